@@ -1,0 +1,159 @@
+/*
+ * ismpc.h -- C ABI of the MI355X-native ISMPC gait-generation hot path.
+ *
+ * This is the drop-in boundary for ONE path of the reference
+ * (FrancescoScotti/Quadruped_gait_generation_ISMPC): the per-tick
+ * `MPCSolver` loop.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference's AMR_code_DART/).
+ *
+ *   ismpc_create        <->  MPCSolver::MPCSolver(const Eigen::MatrixXd&)      MPCSolver.hpp:18, MPCSolver.cpp:5-200
+ *   ismpc_solve_batch*  <->  State MPCSolver::solve(State, WalkState, const&)  MPCSolver.hpp:22, MPCSolver.cpp:204-501
+ *                            (which calls solveQP_hpipm_z                      utils.cpp:264-383
+ *                             and solveQP_hpipm_xy_piecewiseconstantZMP x2     utils.cpp:385-511)
+ *   ismpc_rollout*      <->  the tick bookkeeping around solve()               Controller.cpp:297-310,346-348,503-504
+ *   ismpc_destroy       <->  MPCSolver::~MPCSolver()                           MPCSolver.hpp:19
+ *   ismpc_params        <->  the compile-time constants of                     parameters.cpp:9-45, MPCSolver.cpp:253-255
+ *   ismpc_tick_in/out   <->  the fields of State / WalkState that solve()
+ *                            reads and writes                                  types.hpp:7-12,77-81
+ *
+ * Conventions: plain C types only, no exceptions, int status returns
+ * (0 = ok, negative = ISMPC_E_*), caller owns every buffer, a handle is not
+ * re-entrant (like the reference's MPCSolver, which keeps member scratch) but
+ * distinct handles are independent.  The compute path is HIP on gfx950; there
+ * is NO CPU fallback: without a usable GPU every compute entry point returns
+ * ISMPC_E_NO_DEVICE and ismpc_last_error() says why.
+ */
+#ifndef ISMPC_H
+#define ISMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISMPC_ABI_VERSION 1
+
+/* ---- error codes (function return values) ------------------------------ */
+#define ISMPC_OK              0
+#define ISMPC_E_INVALID      -1   /* bad argument / parameter combination    */
+#define ISMPC_E_NO_DEVICE    -2   /* no HIP device, or HIP runtime error     */
+#define ISMPC_E_ALLOC        -3   /* host or device allocation failed        */
+#define ISMPC_E_NUMERIC      -4   /* vertical Hessian not positive definite  */
+#define ISMPC_E_UNSUPPORTED  -5   /* horizon larger than the kernels cover   */
+
+/* ---- per-instance status bits (ismpc_tick_out.status) -------------------
+ * The reference ignores every solver status (utils.cpp:128,363,491); these
+ * bits exist so that a batch caller can tell which instances left the regime
+ * in which the exact solve and the reference's QP solve coincide.           */
+#define ISMPC_ST_OK            0
+#define ISMPC_ST_X_INFEASIBLE  1   /* horizontal x QP infeasible (qpOASES rv 37)            */
+#define ISMPC_ST_Y_INFEASIBLE  2   /* horizontal y QP infeasible                            */
+#define ISMPC_ST_Z_INEQ_ACTIVE 4   /* 0 <= S u <= 1e4 (MPCSolver.cpp:158-160) was active:
+                                      solved by the dual active-set fallback               */
+#define ISMPC_ST_BAD_INDEX     8   /* midpoint window [idx, idx+2N) outside the plan
+                                      (MPCSolver.cpp:259,381 would read out of range):
+                                      state passed through unchanged                        */
+#define ISMPC_ST_FLIGHT        16  /* lambda_0 <= gate: Stage 3 skipped, u_x = u_y = 0
+                                      (MPCSolver.cpp:322,402-403) -- not an error           */
+#define ISMPC_ST_TICK_SKIPPED  32  /* controlIter % (int)(100 dt) != 0 (MPCSolver.cpp:214):
+                                      state passed through -- not an error                  */
+#define ISMPC_ST_Z_NAN         64  /* NaN guard fired (MPCSolver.cpp:277-278)               */
+#define ISMPC_ST_Z_FAILED      128 /* vertical fallback did not converge / infeasible       */
+
+/* ---- parameters: parameters.cpp:9-45 and MPCSolver.cpp:253-255 ---------- */
+typedef struct ismpc_params {
+    int32_t N;                 /* horizon samples           parameters.cpp:42 (=100)       */
+    int32_t S;                 /* single-support samples    parameters.cpp:43 (=35)        */
+    int32_t F;                 /* double-support samples    parameters.cpp:44 (=10)        */
+    int32_t M;                 /* footsteps in horizon      parameters.cpp:45 (unused by solve) */
+    double  mpc_dt;            /* mpcTimeStep               parameters.cpp:9               */
+    double  control_dt;        /* controlTimeStep           parameters.cpp:10              */
+    double  mass;              /* mass_hrp4                 parameters.cpp:39              */
+    double  g;                 /* g                         parameters.cpp:40              */
+    double  h_des;             /* comTargetHeight           parameters.cpp:16              */
+    double  foot_width;        /* footConstraintSquareWidth parameters.cpp:21              */
+    double  first_step_halfwidth; /* +-1 m box while footstepCounter<=1, MPCSolver.cpp:334-337 */
+    double  q_p, q_u, q_v;     /* vertical QP weights       MPCSolver.cpp:253-255          */
+    double  z_ineq_lo, z_ineq_hi; /* bounds on S_bar_z u    MPCSolver.cpp:159-160          */
+    double  lambda_gate;       /* 2.0                       MPCSolver.cpp:322,353,406      */
+} ismpc_params;
+
+/* Fills *p with the reference's shipped constants (N=100,S=35,F=10,...). */
+void ismpc_params_default(ismpc_params* p);
+
+/* ---- per-instance records ----------------------------------------------
+ * AoS on purpose: one wavefront owns one instance, so the 72-byte input
+ * record is one coalesced read and the 80-byte output record one write.    */
+typedef struct ismpc_tick_in {
+    double  com_pos[3];        /* State::comPos   types.hpp:8  (x,y,z)                      */
+    double  com_vel[3];        /* State::comVel   types.hpp:9                               */
+    double  simulation_time;   /* WalkState::simulationTime  types.hpp:79 (frames)          */
+    int32_t mpc_iter;          /* WalkState::mpcIter         types.hpp:80                   */
+    int32_t control_iter;      /* WalkState::controlIter                                    */
+    int32_t footstep_counter;  /* WalkState::footstepCounter                                */
+    int32_t reserved;          /* keep 0                                                    */
+} ismpc_tick_in;               /* 72 bytes */
+
+typedef struct ismpc_tick_out {
+    double  com_pos[3];        /* next.comPos  MPCSolver.cpp:275,419,421                    */
+    double  com_vel[3];        /* next.comVel  MPCSolver.cpp:276,420,422                    */
+    double  u0[3];             /* first decision variable of the z, x, y QP
+                                  (MPCSolver.cpp:274,402,403): force, ZMP x, ZMP y          */
+    int32_t status;            /* ISMPC_ST_* bits                                           */
+    int32_t iters;             /* x iterations | y iterations << 8 | z fallback its << 16   */
+} ismpc_tick_out;              /* 80 bytes */
+
+typedef struct ismpc_handle ismpc_handle;
+
+/* MPCSolver::MPCSolver (MPCSolver.cpp:5-200).  `ftsp` is the caller's
+ * ftsp_and_timings matrix, rows x 4 row-major (x, y, z, t), as built at
+ * Controller.cpp:89-97.  The plan is captured here exactly as the reference
+ * captures it at construction (solve() never re-reads it, MPCSolver.cpp:441).
+ * `device` is the HIP device ordinal.  Does not read the ../vertical_motion z.txt and f.txt files
+ * (MPCSolver.cpp:8-29 loads them but solve() never uses the values).        */
+int ismpc_create(const ismpc_params* params, const double* ftsp, int rows,
+                 int device, ismpc_handle** out);
+
+void ismpc_destroy(ismpc_handle* h);
+
+/* One MPCSolver::solve per instance, `batch` independent instances.
+ * Host pointers; copies in, runs, copies out, returns when done.           */
+int ismpc_solve_batch(ismpc_handle* h, int batch,
+                      const ismpc_tick_in* in_host, ismpc_tick_out* out_host);
+
+/* Same, device pointers, enqueued on `stream` (a hipStream_t; NULL = the
+ * default stream), asynchronous.  `u_traj` is NULL or a device buffer of
+ * batch x 3 x N doubles receiving the three decision trajectories
+ * (decisionVariables_z/_x/_y, MPCSolver.cpp:269,395,396).                   */
+int ismpc_solve_batch_device(ismpc_handle* h, int batch,
+                             const ismpc_tick_in* in_dev, ismpc_tick_out* out_dev,
+                             double* u_traj, void* stream);
+
+/* Closed loop on the device: for t = 0..ticks-1 run the caller bookkeeping
+ * of Controller.cpp:297-304 (enabled, i.e. without the `&& false`), set
+ * simulationTime = first_frame + t (Controller.cpp:310), solve, feed the
+ * output back as the next input (Controller.cpp:346-348), then
+ * ++controlIter, mpcIter = floor(controlIter*cdt/dt) (Controller.cpp:503-504).
+ * `state` (device, batch records) is updated in place; `traj` is NULL or a
+ * device buffer of ticks x batch ismpc_tick_out records.                    */
+int ismpc_rollout_device(ismpc_handle* h, int batch, ismpc_tick_in* state_dev,
+                         int first_frame, int ticks, ismpc_tick_out* traj_dev,
+                         void* stream);
+
+/* Introspection. */
+int         ismpc_abi_version(void);
+const char* ismpc_last_error(void);        /* thread-local, never NULL */
+int         ismpc_get_params(const ismpc_handle* h, ismpc_params* out);
+int         ismpc_midpoint_rows(const ismpc_handle* h);   /* rows*(S+F), MPCSolver.cpp:167 */
+/* Copies the host copy of ftsp_midpoint (rows*(S+F) x 3 row-major) into dst. */
+int         ismpc_get_midpoint(const ismpc_handle* h, double* dst, int capacity_rows);
+/* Last kernel time of ismpc_solve_batch* in milliseconds measured with HIP
+ * events on the launch stream (0 when timing is disabled).                 */
+int         ismpc_set_timing(ismpc_handle* h, int enabled);
+double      ismpc_last_kernel_ms(ismpc_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISMPC_H */

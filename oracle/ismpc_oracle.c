@@ -1,0 +1,623 @@
+/*
+ * ismpc_oracle.c -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+ *
+ * Plain-C, single-threaded CPU restatement of the reference's ISMPC hot path
+ * ("Formulation B", what MPCSolver::solve executes).  Only tests/, the smoke
+ * check of __graft_entry__.py and the cpu_baseline leg of bench.py may load
+ * this library, and only as the checker.  The product (include/ismpc.h,
+ * quadruped_gait_generation_ismpc_amd/csrc) never links or calls it.
+ *
+ * What it follows, line by line (paths relative to the reference's
+ * AMR_code_DART/):
+ *   orc_create        MPCSolver::MPCSolver          MPCSolver.cpp:124-198  (dense matrices, matrixPower utils.cpp:73-81)
+ *   orc_solve_tick    MPCSolver::solve              MPCSolver.cpp:204-430  (dense assembly of all three QPs)
+ *   orc_rollout       caller bookkeeping            Controller.cpp:297-304,310,346-348,503-504
+ *   QP call shape     solveQP                       utils.cpp:89-139       (stacked lb <= A x <= ub, equalities lb = ub, row-major)
+ *
+ * The QP solver itself is pluggable (orc_set_qp_backend):
+ *   - oracle/_ref/libqpoases_ref.so : the reference's own vendored qpOASES 3.2
+ *     compiled in place from /root/reference (oracle/Makefile) and called
+ *     with the reference's solveQP settings.  This is the pin.
+ *   - orc_qp_gi (below): a dense Goldfarb-Idnani dual active-set solver, a
+ *     textbook algorithm written for this file, used when the _ref library
+ *     is not present and cross-checked against it in tests/.
+ * The reference's solve() calls HPIPM (utils.cpp:264-511), which is neither
+ * vendored nor pinned; every QP on this path is strictly convex, so the
+ * minimiser is unique and solver independent -- parity is defined against
+ * the vendored qpOASES solve of the same QP data.
+ *
+ * Deliberately dense and naive: it builds H_z, S_bar_z, phi_input ... as the
+ * reference does, so that it shares no algebraic shortcut with the HIP path.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "../include/ismpc.h"   /* record layouts and status bits only */
+
+typedef int (*orc_qp_fn)(int nV, int nC, const double* H, const double* g,
+                         const double* A, const double* lbA, const double* ubA,
+                         double* x, int* nWSR);
+
+typedef struct orc_solver {
+    ismpc_params p;
+    double eta;
+    int rows, nmid;
+    double *ftsp;                       /* rows x 4 */
+    double *S_z, *S_zv, *S_gz, *S_gzv;  /* N x N  (S_bar_z, S_bar_z_v, S_bar_g_z, S_bar_g_z_v) */
+    double *T_z, *T_zv;                 /* N x 2 */
+    double *T_gz, *T_gzv;               /* N */
+    double *H_z;                        /* N x N */
+    double *mid;                        /* nmid x 3 (ftsp_midpoint) */
+    double *deltas;                     /* N */
+    orc_qp_fn qp;
+} orc_solver;
+
+typedef struct orc_tick_info {
+    int rv[3];        /* solver return value for z, x, y (0 ok, 37 infeasible, 64 nWSR) ; -1 = not run */
+    int nwsr[3];
+    int idx;
+    int ne_z;         /* equality rows handed to the z QP */
+    double lambda0;
+    double beq[2];
+} orc_tick_info;
+
+int orc_qp_gi(int n, int nC, const double* H, const double* g0, const double* A,
+              const double* lbA, const double* ubA, double* x, int* nWSR);
+
+/* ---------------------------------------------------------------------- */
+/* utils.cpp:73-81  matrixPower, 2x2, by repeated multiplication          */
+static void mat2_power(const double A[4], int e, double R[4])
+{
+    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 1;
+    for (int i = 0; i < e; ++i) {
+        double t0 = R[0]*A[0] + R[1]*A[2], t1 = R[0]*A[1] + R[1]*A[3];
+        double t2 = R[2]*A[0] + R[3]*A[2], t3 = R[2]*A[1] + R[3]*A[3];
+        R[0] = t0; R[1] = t1; R[2] = t2; R[3] = t3;
+    }
+}
+
+void orc_destroy(orc_solver* s)
+{
+    if (!s) return;
+    free(s->ftsp); free(s->S_z); free(s->S_zv); free(s->S_gz); free(s->S_gzv);
+    free(s->T_z); free(s->T_zv); free(s->T_gz); free(s->T_gzv); free(s->H_z);
+    free(s->mid); free(s->deltas); free(s);
+}
+
+/* MPCSolver::MPCSolver, MPCSolver.cpp:124-198 */
+orc_solver* orc_create(const ismpc_params* p, const double* ftsp, int rows)
+{
+    if (!p || !ftsp || rows < 2 || p->N < 1 || p->S < 0 || p->F < 1) return NULL;
+    orc_solver* s = (orc_solver*)calloc(1, sizeof(*s));
+    s->p = *p;
+    s->eta = sqrt(p->g / p->h_des);                       /* parameters.cpp:41 */
+    s->rows = rows;
+    const int N = p->N, S = p->S, F = p->F;
+    const double dt = p->mpc_dt, m = p->mass;
+    s->nmid = rows * (S + F);
+    s->ftsp = (double*)malloc(sizeof(double) * rows * 4);
+    memcpy(s->ftsp, ftsp, sizeof(double) * rows * 4);
+    s->S_z = (double*)calloc((size_t)N*N, 8);  s->S_zv = (double*)calloc((size_t)N*N, 8);
+    s->S_gz = (double*)calloc((size_t)N*N, 8); s->S_gzv = (double*)calloc((size_t)N*N, 8);
+    s->T_z = (double*)calloc((size_t)N*2, 8);  s->T_zv = (double*)calloc((size_t)N*2, 8);
+    s->T_gz = (double*)calloc(N, 8);           s->T_gzv = (double*)calloc(N, 8);
+    s->H_z = (double*)calloc((size_t)N*N, 8);
+    s->mid = (double*)calloc((size_t)s->nmid*3, 8);
+    s->deltas = (double*)calloc(N, 8);
+    s->qp = orc_qp_gi;
+
+    /* :124-130 */
+    const double A_z[4] = {1.0, dt, 0.0, 1.0};
+    const double B_z[2] = {0.0, dt / m};
+    const double Bg_z[2] = {0.0, -dt};
+    /* :144-154 */
+    for (int k = 0; k < N; ++k) {
+        double P[4];
+        mat2_power(A_z, k + 1, P);
+        s->T_z[k*2+0] = P[0];  s->T_z[k*2+1] = P[1];      /* C_z = [1 0] */
+        s->T_zv[k*2+0] = P[2]; s->T_zv[k*2+1] = P[3];     /* C_v = [0 1] */
+        for (int j = 0; j < k; ++j) {
+            mat2_power(A_z, k - j, P);
+            s->S_z[k*N+j]   = P[0]*B_z[0]  + P[1]*B_z[1];
+            s->S_zv[k*N+j]  = P[2]*B_z[0]  + P[3]*B_z[1];
+            s->S_gz[k*N+j]  = P[0]*Bg_z[0] + P[1]*Bg_z[1];
+            s->S_gzv[k*N+j] = P[2]*Bg_z[0] + P[3]*Bg_z[1];
+        }
+    }
+    /* :155-156  T_bar_g_z = S_bar_g_z * p * g */
+    for (int k = 0; k < N; ++k) {
+        double a = 0, b = 0;
+        for (int j = 0; j < N; ++j) { a += s->S_gz[k*N+j]; b += s->S_gzv[k*N+j]; }
+        s->T_gz[k] = a * p->g; s->T_gzv[k] = b * p->g;
+    }
+    /* MPCSolver.cpp:258 -- constant, so it is formed once here */
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            double a = 0, b = 0;
+            for (int k = 0; k < N; ++k) {
+                a += s->S_z[k*N+i]  * s->S_z[k*N+j];
+                b += s->S_zv[k*N+i] * s->S_zv[k*N+j];
+            }
+            s->H_z[i*N+j] = p->q_p * a + p->q_v * b + (i == j ? p->q_u : 0.0);
+        }
+    /* :167-180 ftsp_midpoint */
+    for (int i = 0; i < rows - 1; ++i) {
+        for (int c = 0; c < 3; ++c) {
+            double a = ftsp[i*4+c], b = ftsp[(i+1)*4+c];
+            for (int r = 0; r < S; ++r) s->mid[(i*(S+F)+r)*3+c] = a * 1.0;
+            for (int r = 0; r < F; ++r)
+                s->mid[(i*(S+F)+S+r)*3+c] = a * 1.0 + (b - a) * ((double)r / (double)F);
+        }
+    }
+    /* :183-184 */
+    for (int i = 0; i < N; ++i) s->deltas[i] = exp(-dt * s->eta * i);
+    return s;
+}
+
+void orc_set_qp_backend(orc_solver* s, orc_qp_fn fn) { s->qp = fn ? fn : orc_qp_gi; }
+int  orc_midpoint_rows(const orc_solver* s) { return s->nmid; }
+const double* orc_midpoint(const orc_solver* s) { return s->mid; }
+const double* orc_Hz(const orc_solver* s) { return s->H_z; }
+
+/* MPCSolver::solve, MPCSolver.cpp:204-430.  u_traj: NULL or 3*N doubles (z, x, y). */
+int orc_solve_tick(orc_solver* s, const ismpc_tick_in* in, ismpc_tick_out* out,
+                   double* u_traj, orc_tick_info* info)
+{
+    const ismpc_params* p = &s->p;
+    const int N = p->N, S = p->S, F = p->F;
+    const double dt = p->mpc_dt, m = p->mass, g = p->g, eta = s->eta;
+    orc_tick_info li; if (!info) info = &li;
+    memset(info, 0, sizeof(*info));
+    info->rv[0] = info->rv[1] = info->rv[2] = -1;
+
+    /* :210 next = current */
+    for (int c = 0; c < 3; ++c) { out->com_pos[c] = in->com_pos[c]; out->com_vel[c] = in->com_vel[c]; out->u0[c] = 0.0; }
+    out->status = 0; out->iters = 0;
+    if (u_traj) memset(u_traj, 0, sizeof(double) * 3 * N);
+
+    /* :214 */
+    int divisor = (int)(100 * dt);
+    if (divisor <= 0 || (in->control_iter % divisor) != 0) { out->status |= ISMPC_ST_TICK_SKIPPED; return 0; }
+
+    /* index used at :259,329-337,381-389 */
+    int idx = (int)(in->simulation_time / (dt / p->control_dt));
+    info->idx = idx;
+    if (idx < 0 || idx + 2 * N > s->nmid) { out->status |= ISMPC_ST_BAD_INDEX; return 0; }
+
+    /* ---- STAGE ONE, :220-278 ---- */
+    int ne = (in->mpc_iter < S) ? F : (S + F - in->mpc_iter);
+    if (ne < 0) ne = 0;
+    double* Aeq_z = (double*)calloc((size_t)(ne > 0 ? ne : 1) * N, 8);
+    for (int i = 0; i < N; ++i) {
+        if (in->mpc_iter < S) {
+            if (i >= S && i < S + F) {
+                int r = i - S, c = i - in->mpc_iter;
+                if (r < ne && c >= 0 && c < N) Aeq_z[r*N + c] = 1.0;
+            }
+        } else {
+            if (i < S + F - in->mpc_iter) Aeq_z[i*N + i] = 1.0;
+        }
+    }
+    double sz[2] = { in->com_pos[2], in->com_vel[2] };
+    /* :259 */
+    double* rp = (double*)malloc(sizeof(double) * N);
+    double* rv = (double*)malloc(sizeof(double) * N);
+    double* f_z = (double*)malloc(sizeof(double) * N);
+    for (int k = 0; k < N; ++k) {
+        rp[k] = (s->T_z[k*2]*sz[0] + s->T_z[k*2+1]*sz[1]) + s->T_gz[k] - 1.0*p->h_des - s->mid[(idx+k)*3+2];
+        rv[k] = (s->T_zv[k*2]*sz[0] + s->T_zv[k*2+1]*sz[1]) + s->T_gzv[k];
+    }
+    for (int i = 0; i < N; ++i) {
+        double a = 0, b = 0;
+        for (int k = 0; k < N; ++k) { a += s->S_z[k*N+i] * rp[k]; b += s->S_zv[k*N+i] * rv[k]; }
+        f_z[i] = p->q_p * a + p->q_v * b + p->q_u * (-1.0 * m * g);
+    }
+    /* :262-263 */
+    double is_running = (in->footstep_counter > 1) ? 1.0 : 0.0;
+
+    /* stack the QP the way solveQP (utils.cpp:89-139) expects it: equality
+     * rows first as lb = ub, then the N rows of Aineq_z = S_bar_z.  Rows of
+     * is_running*Aeq_z that are identically zero (is_running = 0, or a unit
+     * column that falls outside the horizon) are dropped: same minimiser. */
+    int nC = 0;
+    double* Astk = (double*)calloc((size_t)(ne + N) * N, 8);
+    double* lb = (double*)malloc(sizeof(double) * (ne + N));
+    double* ub = (double*)malloc(sizeof(double) * (ne + N));
+    for (int r = 0; r < ne; ++r) {
+        int nz = 0;
+        for (int c = 0; c < N; ++c) { double v = is_running * Aeq_z[r*N+c]; Astk[nC*N+c] = v; if (v != 0.0) nz = 1; }
+        if (nz) { lb[nC] = 0.0; ub[nC] = 0.0; ++nC; }
+        else memset(&Astk[nC*N], 0, sizeof(double) * N);
+    }
+    info->ne_z = nC;
+    for (int k = 0; k < N; ++k) {
+        memcpy(&Astk[nC*N], &s->S_z[k*N], sizeof(double) * N);
+        lb[nC] = p->z_ineq_lo; ub[nC] = p->z_ineq_hi; ++nC;
+    }
+    double* u_z = (double*)calloc(N, 8);
+    int nwsr = 300;
+    info->rv[0] = s->qp(N, nC, s->H_z, f_z, Astk, lb, ub, u_z, &nwsr);
+    info->nwsr[0] = nwsr;
+    if (info->rv[0] != 0) out->status |= ISMPC_ST_Z_FAILED;
+
+    /* :274-278 */
+    out->com_pos[2] = (1.0*sz[0] + dt*sz[1]) + 0.0*u_z[0] + 0.0*g;
+    out->com_vel[2] = (0.0*sz[0] + 1.0*sz[1]) + (dt/m)*u_z[0] + (-dt)*g;
+    if (isnan(out->com_pos[2])) { out->com_pos[2] = p->h_des; out->status |= ISMPC_ST_Z_NAN; }
+    if (isnan(out->com_vel[2])) { out->com_vel[2] = 0.0;      out->status |= ISMPC_ST_Z_NAN; }
+    out->u0[0] = u_z[0];
+
+    /* ---- STAGE TWO, :296-309 ---- */
+    double* lambda = (double*)malloc(sizeof(double) * N);
+    for (int j = 0; j < N; ++j) {
+        double zacc = (1.0/m) * u_z[j] - 1.0*g;
+        double zpos = 0;
+        for (int k = 0; k < N; ++k) zpos += s->S_z[j*N+k] * u_z[k];
+        zpos += s->T_z[j*2]*sz[0] + s->T_z[j*2+1]*sz[1];
+        zpos += s->T_gz[j];
+        lambda[j] = (g + zacc) / zpos;
+        /* inequality activity (reported, not part of the reference) */
+        if (j >= 1) {
+            double su = 0; for (int k = 0; k < N; ++k) su += s->S_z[j*N+k] * u_z[k];
+            if (su <= p->z_ineq_lo + 1e-9 || su >= p->z_ineq_hi - 1e-9) out->status |= ISMPC_ST_Z_INEQ_ACTIVE;
+        }
+    }
+    info->lambda0 = lambda[0];
+
+    /* ---- STAGE THREE, :314-398 ---- */
+    double sx[2] = { in->com_pos[0], in->com_vel[0] };
+    double sy[2] = { in->com_pos[1], in->com_vel[1] };
+    double* u_x = (double*)calloc(N, 8);
+    double* u_y = (double*)calloc(N, 8);
+    const double gate = p->lambda_gate;
+
+    if (lambda[0] > gate) {
+        double half = (in->footstep_counter > 1) ? p->foot_width / 2 : p->first_step_halfwidth;
+        double *Zmin_x = (double*)malloc(8*N), *Zmax_x = (double*)malloc(8*N);
+        double *Zmin_y = (double*)malloc(8*N), *Zmax_y = (double*)malloc(8*N);
+        for (int k = 0; k < N; ++k) {
+            Zmin_x[k] = s->mid[(idx+k)*3+0] - 1.0*half; Zmax_x[k] = s->mid[(idx+k)*3+0] + 1.0*half;
+            Zmin_y[k] = s->mid[(idx+k)*3+1] - 1.0*half; Zmax_y[k] = s->mid[(idx+k)*3+1] + 1.0*half;
+        }
+        /* :349-373 */
+        double phi_state[4] = {1, 0, 0, 1};
+        double* phi_input = (double*)calloc((size_t)2*N, 8);   /* 2 x N */
+        for (int i = 0; i < N; ++i) {
+            double Axy[4], Bxy[2];
+            if (lambda[i] < gate) { Axy[0]=1.0; Axy[1]=dt; Axy[2]=0.0; Axy[3]=1.0; Bxy[0]=0.0; Bxy[1]=0.0; }
+            else {
+                double sq = sqrt(lambda[i]);
+                double ch = cosh(sq*dt), sh = sinh(sq*dt);
+                Axy[0]=ch; Axy[1]=sh/sq; Axy[2]=sq*sh; Axy[3]=ch;
+                Bxy[0]=1-ch; Bxy[1]=-sq*sh;
+            }
+            double t0 = Axy[0]*phi_state[0] + Axy[1]*phi_state[2], t1 = Axy[0]*phi_state[1] + Axy[1]*phi_state[3];
+            double t2 = Axy[2]*phi_state[0] + Axy[3]*phi_state[2], t3 = Axy[2]*phi_state[1] + Axy[3]*phi_state[3];
+            phi_state[0]=t0; phi_state[1]=t1; phi_state[2]=t2; phi_state[3]=t3;
+            double c0 = Bxy[0], c1 = Bxy[1];
+            for (int j = i + 1; j < N; ++j) {
+                double sq = sqrt(lambda[j]);
+                double ch = cosh(sq*dt), sh = sinh(sq*dt);
+                double A0=ch, A1=sh/sq, A2=sq*sh, A3=ch;
+                if (lambda[j] < gate) { A0=1; A1=dt; A2=0; A3=1; }
+                double n0 = A0*c0 + A1*c1, n1 = A2*c0 + A3*c1;
+                c0 = n0; c1 = n1;
+            }
+            phi_input[0*N+i] = c0; phi_input[1*N+i] = c1;
+        }
+        /* :375-384 */
+        double eta_sc = eta;
+        double Csc[2] = {1.0, 1.0/eta_sc};
+        double* Aeq = (double*)malloc(8*N);
+        for (int i = 0; i < N; ++i) Aeq[i] = Csc[0]*phi_input[i] + Csc[1]*phi_input[N+i];
+        double cps0 = Csc[0]*phi_state[0] + Csc[1]*phi_state[2];
+        double cps1 = Csc[0]*phi_state[1] + Csc[1]*phi_state[3];
+        double tail_x = 0, tail_y = 0;
+        for (int i = 0; i < N; ++i) {
+            tail_x += (eta_sc*dt*s->deltas[i]) * s->mid[(idx+N+i)*3+0];
+            tail_y += (eta_sc*dt*s->deltas[i]) * s->mid[(idx+N+i)*3+1];
+        }
+        double beq_x = -(cps0*sx[0] + cps1*sx[1]) + tail_x;
+        double beq_y = -(cps0*sy[0] + cps1*sy[1]) + tail_y;
+        info->beq[0] = beq_x; info->beq[1] = beq_y;
+
+        /* :388-396  H = I, f = -mid, 1 equality row + N identity rows */
+        int nCx = N + 1;
+        double* Hxy = (double*)calloc((size_t)N*N, 8);
+        double* Ax  = (double*)calloc((size_t)nCx*N, 8);
+        double *lbx = (double*)malloc(8*nCx), *ubx = (double*)malloc(8*nCx);
+        double *fx = (double*)malloc(8*N), *fy = (double*)malloc(8*N);
+        for (int i = 0; i < N; ++i) {
+            Hxy[i*N+i] = 1.0;
+            Ax[i] = Aeq[i];
+            Ax[(1+i)*N+i] = 1.0;
+            fx[i] = -s->mid[(idx+i)*3+0]; fy[i] = -s->mid[(idx+i)*3+1];
+        }
+        lbx[0] = ubx[0] = beq_x;
+        for (int i = 0; i < N; ++i) { lbx[1+i] = Zmin_x[i]; ubx[1+i] = Zmax_x[i]; }
+        nwsr = 300;
+        info->rv[1] = s->qp(N, nCx, Hxy, fx, Ax, lbx, ubx, u_x, &nwsr); info->nwsr[1] = nwsr;
+        lbx[0] = ubx[0] = beq_y;
+        for (int i = 0; i < N; ++i) { lbx[1+i] = Zmin_y[i]; ubx[1+i] = Zmax_y[i]; }
+        nwsr = 300;
+        info->rv[2] = s->qp(N, nCx, Hxy, fy, Ax, lbx, ubx, u_y, &nwsr); info->nwsr[2] = nwsr;
+        if (info->rv[1] != 0) out->status |= ISMPC_ST_X_INFEASIBLE;
+        if (info->rv[2] != 0) out->status |= ISMPC_ST_Y_INFEASIBLE;
+
+        free(Zmin_x); free(Zmax_x); free(Zmin_y); free(Zmax_y); free(phi_input); free(Aeq);
+        free(Hxy); free(Ax); free(lbx); free(ubx); free(fx); free(fy);
+    } else {
+        out->status |= ISMPC_ST_FLIGHT;
+    }
+
+    /* :402-422 */
+    double zx = u_x[0], zy = u_y[0];
+    double Axy[4], Bxy[2];
+    if (lambda[0] < gate) { Axy[0]=1.0; Axy[1]=dt; Axy[2]=0.0; Axy[3]=1.0; Bxy[0]=0.0; Bxy[1]=0.0; }
+    else {
+        double sq = sqrt(lambda[0]);
+        double ch = cosh(sq*dt), sh = sinh(sq*dt);
+        Axy[0]=ch; Axy[1]=sh/sq; Axy[2]=sq*sh; Axy[3]=ch;
+        Bxy[0]=1.0-ch; Bxy[1]=-sq*sh;
+    }
+    out->com_pos[0] = (Axy[0]*sx[0] + Axy[1]*sx[1]) + Bxy[0]*zx;
+    out->com_vel[0] = (Axy[2]*sx[0] + Axy[3]*sx[1]) + Bxy[1]*zx;
+    out->com_pos[1] = (Axy[0]*sy[0] + Axy[1]*sy[1]) + Bxy[0]*zy;
+    out->com_vel[1] = (Axy[2]*sy[0] + Axy[3]*sy[1]) + Bxy[1]*zy;
+    out->u0[1] = zx; out->u0[2] = zy;
+
+    if (u_traj) {
+        memcpy(u_traj, u_z, 8*N); memcpy(u_traj + N, u_x, 8*N); memcpy(u_traj + 2*N, u_y, 8*N);
+    }
+    free(Aeq_z); free(rp); free(rv); free(f_z); free(Astk); free(lb); free(ub);
+    free(u_z); free(lambda); free(u_x); free(u_y);
+    return 0;
+}
+
+int orc_solve_batch(orc_solver* s, int batch, const ismpc_tick_in* in, ismpc_tick_out* out,
+                    double* u_traj, orc_tick_info* info)
+{
+    for (int b = 0; b < batch; ++b)
+        orc_solve_tick(s, &in[b], &out[b], u_traj ? u_traj + (size_t)b*3*s->p.N : NULL, info ? &info[b] : NULL);
+    return 0;
+}
+
+/* Caller bookkeeping, Controller.cpp:297-304 (enabled), :310, :346-348, :503-504.
+ * state->simulation_time holds the value assigned at the previous frame (the
+ * reference tests it BEFORE re-assigning it at :310). */
+void orc_bookkeeping_pre(const orc_solver* s, ismpc_tick_in* st, int frame)
+{
+    int fc = st->footstep_counter;
+    if (fc >= 0 && fc < s->rows && st->simulation_time >= s->ftsp[fc*4+3] - 1) {   /* :297 */
+        st->control_iter = 0; st->mpc_iter = 0; st->footstep_counter = fc + 1;      /* :298-300 */
+    }
+    st->simulation_time = (double)frame;                                            /* :310 */
+}
+void orc_bookkeeping_post(const orc_solver* s, ismpc_tick_in* st)
+{
+    ++st->control_iter;                                                             /* :503 */
+    st->mpc_iter = (int)floor(st->control_iter * s->p.control_dt / s->p.mpc_dt);    /* :504 */
+}
+
+int orc_rollout(orc_solver* s, ismpc_tick_in* st, int first_frame, int ticks,
+                ismpc_tick_out* traj, ismpc_tick_in* in_traj, orc_tick_info* info_traj)
+{
+    for (int t = 0; t < ticks; ++t) {
+        ismpc_tick_out o; orc_tick_info inf;
+        orc_bookkeeping_pre(s, st, first_frame + t);
+        if (in_traj) in_traj[t] = *st;
+        orc_solve_tick(s, st, &o, NULL, &inf);
+        for (int c = 0; c < 3; ++c) { st->com_pos[c] = o.com_pos[c]; st->com_vel[c] = o.com_vel[c]; }  /* :348 */
+        if (traj) traj[t] = o;
+        if (info_traj) info_traj[t] = inf;
+        orc_bookkeeping_post(s, st);
+    }
+    return 0;
+}
+
+/* ====================================================================== */
+/* Dense Goldfarb-Idnani dual active-set QP solver (own implementation of
+ * the published algorithm: Goldfarb & Idnani, Math. Prog. 27 (1983) 1-33).
+ *   min 1/2 x'Hx + g'x   s.t.  lbA <= A x <= ubA   (A row-major nC x n)
+ * rows with lbA == ubA are equalities; |bound| >= 1e20 means absent.
+ * Same signature and return codes as the qpOASES shim (0 ok, 37 infeasible,
+ * 64 iteration limit, 33 Hessian not positive definite).                  */
+#define GI_INF 1e20
+
+static void gi_delete(int n, int l, int* q, double* R, double* J, double* u, int* act)
+{
+    int qq = *q;
+    for (int i = l; i < qq - 1; ++i) {
+        act[i] = act[i+1]; u[i] = u[i+1];
+        for (int j = 0; j < n; ++j) R[j*n+i] = R[j*n+i+1];
+    }
+    act[qq-1] = -1; u[qq-1] = 0;
+    for (int j = 0; j < n; ++j) R[j*n+qq-1] = 0;
+    --qq; *q = qq;
+    for (int i = l; i < qq; ++i) {
+        double a = R[i*n+i], b = R[(i+1)*n+i];
+        double h = hypot(a, b);
+        if (h == 0.0) continue;
+        double c = a / h, s_ = b / h;
+        for (int k = i; k < qq; ++k) {
+            double r0 = R[i*n+k], r1 = R[(i+1)*n+k];
+            R[i*n+k] = c*r0 + s_*r1; R[(i+1)*n+k] = -s_*r0 + c*r1;
+        }
+        R[(i+1)*n+i] = 0.0;
+        for (int k = 0; k < n; ++k) {
+            double j0 = J[k*n+i], j1 = J[k*n+i+1];
+            J[k*n+i] = c*j0 + s_*j1; J[k*n+i+1] = -s_*j0 + c*j1;
+        }
+    }
+}
+
+static int gi_add(int n, int* q, double* R, double* J, double* d, double* rnorm)
+{
+    int qq = *q;
+    for (int j = n - 1; j > qq; --j) {
+        double a = d[j-1], b = d[j];
+        double h = hypot(a, b);
+        if (h == 0.0) continue;
+        double c = a / h, s_ = b / h;
+        d[j-1] = h; d[j] = 0.0;
+        for (int k = 0; k < n; ++k) {
+            double j0 = J[k*n+j-1], j1 = J[k*n+j];
+            J[k*n+j-1] = c*j0 + s_*j1; J[k*n+j] = -s_*j0 + c*j1;
+        }
+    }
+    for (int i = 0; i <= qq; ++i) R[i*n+qq] = d[i];
+    if (fabs(d[qq]) <= 2.3e-16 * (*rnorm) * 100.0) return 0;
+    if (fabs(d[qq]) > *rnorm) *rnorm = fabs(d[qq]);
+    *q = qq + 1;
+    return 1;
+}
+
+int orc_qp_gi(int n, int nC, const double* H, const double* g0, const double* A,
+              const double* lbA, const double* ubA, double* x, int* nWSR)
+{
+    int ret = 0, iter = 0, maxit = (nWSR && *nWSR > 0) ? *nWSR + 2*n + 10 : 10*(n + nC) + 100;
+    if (maxit < 4*(n+nC)) maxit = 4*(n+nC);
+    double* L = (double*)malloc(sizeof(double)*n*n);
+    double* J = (double*)calloc((size_t)n*n, 8);
+    double* R = (double*)calloc((size_t)n*n, 8);
+    double* d = (double*)malloc(8*n), *z = (double*)malloc(8*n), *r = (double*)malloc(8*n);
+    double* u = (double*)calloc(n + 1, 8), *np = (double*)malloc(8*n);
+    int* act = (int*)malloc(sizeof(int)*(n + 1));
+    /* constraint table: c -> (row, sign, rhs): sign*(A_row x) >= rhs */
+    int* crow = (int*)malloc(sizeof(int)*2*(nC+1)); int* csgn = (int*)malloc(sizeof(int)*2*(nC+1));
+    double* crhs = (double*)malloc(8*2*(nC+1)); char* cact = (char*)calloc(2*(nC+1), 1);
+    int* eqrow = (int*)malloc(sizeof(int)*(nC+1));
+    int nI = 0, nE = 0, q = 0, neq_act = 0;
+    memcpy(L, H, sizeof(double)*n*n);
+    /* Cholesky, lower */
+    for (int j = 0; j < n; ++j) {
+        double sum = L[j*n+j];
+        for (int k = 0; k < j; ++k) sum -= L[j*n+k]*L[j*n+k];
+        if (!(sum > 0.0)) { ret = 33; goto done; }
+        double ljj = sqrt(sum); L[j*n+j] = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            double s_ = L[i*n+j];
+            for (int k = 0; k < j; ++k) s_ -= L[i*n+k]*L[j*n+k];
+            L[i*n+j] = s_ / ljj;
+        }
+    }
+    /* J = L^-T : column j solves L' y = e_j (upper triangular result) */
+    for (int j = 0; j < n; ++j) {
+        for (int i = n - 1; i >= 0; --i) {
+            double s_ = (i == j) ? 1.0 : 0.0;
+            for (int k = i + 1; k < n; ++k) s_ -= L[k*n+i]*J[k*n+j];
+            J[i*n+j] = s_ / L[i*n+i];
+        }
+    }
+    /* x = -H^-1 g0 */
+    for (int i = 0; i < n; ++i) {
+        double s_ = -g0[i];
+        for (int k = 0; k < i; ++k) s_ -= L[i*n+k]*z[k];
+        z[i] = s_ / L[i*n+i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s_ = z[i];
+        for (int k = i + 1; k < n; ++k) s_ -= L[k*n+i]*x[k];
+        x[i] = s_ / L[i*n+i];
+    }
+    double rnorm = 1.0;
+    for (int c = 0; c < nC; ++c) {
+        double lo = lbA[c], hi = ubA[c];
+        if (lo > -GI_INF && hi < GI_INF && hi - lo <= 1e-12 * fmax(1.0, fabs(lo))) { eqrow[nE++] = c; continue; }
+        if (lo > hi) { ret = 37; goto done; }
+        if (lo > -GI_INF) { crow[nI] = c; csgn[nI] = +1; crhs[nI] = lo;  ++nI; }
+        if (hi <  GI_INF) { crow[nI] = c; csgn[nI] = -1; crhs[nI] = -hi; ++nI; }
+    }
+    for (int i = 0; i <= n; ++i) act[i] = -1;
+
+    /* equalities */
+    for (int e = 0; e < nE; ++e) {
+        const double* a = &A[(size_t)eqrow[e]*n];
+        double anorm = 0; for (int k = 0; k < n; ++k) anorm += a[k]*a[k];
+        anorm = sqrt(anorm);
+        double res = -lbA[eqrow[e]]; for (int k = 0; k < n; ++k) res += a[k]*x[k];   /* a.x - b */
+        for (int i = 0; i < n; ++i) { double s_ = 0; for (int k = 0; k < n; ++k) s_ += J[k*n+i]*a[k]; d[i] = s_; }
+        for (int i = 0; i < n; ++i) { double s_ = 0; for (int k = q; k < n; ++k) s_ += J[i*n+k]*d[k]; z[i] = s_; }
+        for (int i = q - 1; i >= 0; --i) { double s_ = d[i]; for (int k = i + 1; k < q; ++k) s_ -= R[i*n+k]*r[k]; r[i] = s_ / R[i*n+i]; }
+        double zn = 0, za = 0; for (int k = 0; k < n; ++k) { zn += z[k]*z[k]; za += z[k]*a[k]; }
+        if (sqrt(zn) <= 1e-13 * fmax(1e-300, anorm) * fmax(1.0, rnorm) || anorm == 0.0) {
+            /* dependent (or zero) equality row: consistent -> skip, else infeasible */
+            if (fabs(res) <= 1e-9 * fmax(1.0, fabs(lbA[eqrow[e]]))) continue;
+            ret = 37; goto done;
+        }
+        double t2 = -res / za;
+        for (int k = 0; k < n; ++k) x[k] += t2 * z[k];
+        for (int k = 0; k < q; ++k) u[k] -= t2 * r[k];
+        u[q] = t2; act[q] = -2 - eqrow[e];
+        if (!gi_add(n, &q, R, J, d, &rnorm)) { ret = 37; goto done; }
+        ++neq_act;
+    }
+
+    /* main loop */
+    for (;;) {
+        if (++iter > maxit) { ret = 64; break; }
+        /* most violated inactive inequality (normalised by row norm) */
+        int ip = -1; double worst = 0.0;
+        for (int c = 0; c < nI; ++c) {
+            if (cact[c]) continue;
+            const double* a = &A[(size_t)crow[c]*n];
+            double s_ = 0, an = 0, xs = 0;
+            for (int k = 0; k < n; ++k) { s_ += a[k]*x[k]; an += a[k]*a[k]; xs += fabs(a[k]*x[k]); }
+            s_ = csgn[c]*s_ - crhs[c];
+            double tol = 1e-11 * (fabs(crhs[c]) + xs) + 1e-13;
+            if (s_ < -tol) {
+                double v = (an > 0) ? s_ / sqrt(an) : s_;
+                if (v < worst) { worst = v; ip = c; }
+            }
+        }
+        if (ip < 0) break;
+        const double* a = &A[(size_t)crow[ip]*n];
+        for (int k = 0; k < n; ++k) np[k] = csgn[ip]*a[k];
+        u[q] = 0.0; act[q] = ip;
+        int guard = 0;
+        for (;;) {
+            if (++guard > 4*(n + nC) + 50) { ret = 64; goto done; }
+            double sviol = -crhs[ip]; for (int k = 0; k < n; ++k) sviol += np[k]*x[k];
+            for (int i = 0; i < n; ++i) { double s_ = 0; for (int k = 0; k < n; ++k) s_ += J[k*n+i]*np[k]; d[i] = s_; }
+            for (int i = 0; i < n; ++i) { double s_ = 0; for (int k = q; k < n; ++k) s_ += J[i*n+k]*d[k]; z[i] = s_; }
+            for (int i = q - 1; i >= 0; --i) { double s_ = d[i]; for (int k = i + 1; k < q; ++k) s_ -= R[i*n+k]*r[k]; r[i] = s_ / R[i*n+i]; }
+            /* dual step length */
+            double t1 = INFINITY; int l = -1;
+            for (int k = neq_act; k < q; ++k)
+                if (r[k] > 0.0) { double t = u[k] / r[k]; if (t < t1) { t1 = t; l = k; } }
+            double zn = 0, znp = 0, npn = 0;
+            for (int k = 0; k < n; ++k) { zn += z[k]*z[k]; znp += z[k]*np[k]; npn += np[k]*np[k]; }
+            double t2 = INFINITY;
+            if (sqrt(zn) > 1e-13 * sqrt(npn) * fmax(1.0, rnorm) && znp > 0.0) t2 = -sviol / znp;
+            double t = (t1 < t2) ? t1 : t2;
+            if (!isfinite(t)) { ret = 37; goto done; }
+            if (!isfinite(t2)) {
+                for (int k = 0; k < q; ++k) u[k] -= t * r[k];
+                u[q] += t;
+                cact[act[l]] = 0;
+                { double uq = u[q]; int aq = act[q]; gi_delete(n, l, &q, R, J, u, act); u[q] = uq; act[q] = aq; u[q+1] = 0; act[q+1] = -1; }
+                continue;
+            }
+            for (int k = 0; k < n; ++k) x[k] += t * z[k];
+            for (int k = 0; k < q; ++k) u[k] -= t * r[k];
+            u[q] += t;
+            if (t == t2) {
+                if (!gi_add(n, &q, R, J, d, &rnorm)) {
+                    /* numerically dependent: treat as satisfied */
+                    act[q] = -1; u[q] = 0;
+                    break;
+                }
+                cact[ip] = 1;
+                break;
+            }
+            cact[act[l]] = 0;
+            { double uq = u[q]; int aq = act[q]; gi_delete(n, l, &q, R, J, u, act); u[q] = uq; act[q] = aq; u[q+1] = 0; act[q+1] = -1; }
+        }
+    }
+done:
+    if (nWSR) *nWSR = iter > 0 ? iter - 1 : 0;
+    free(L); free(J); free(R); free(d); free(z); free(r); free(u); free(np); free(act);
+    free(crow); free(csgn); free(crhs); free(cact); free(eqrow);
+    return ret;
+}
