@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- ISMPC tick throughput on MI355X (see the contract in DESIGN.md section "Measurement").
+
+One "step" = one pass of the hot path (one MPCSolver::solve tick, reference MPCSolver.cpp:204-430)
+over one batch of synthetic instances already resident in HBM.  Per-GPU work is fixed (weak
+scaling): each rank owns a contiguous shard of `--batch-per-gpu` instances (default 8 192 = the
+shard of BASELINE config 3, 65 536 instances over 8 GPUs); with more than one rank a step ends with
+the single RCCL all-gather of the 80-byte output records the north star prescribes.
+
+    python bench.py                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP64_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD spec; MI355X_MICROARCH.md lists the FP32 157.3)
+HORIZON = 100
+
+
+def algorithmic_flops_per_tick(N):
+    """SURVEY.md 8d, vertical Hessian factor shared by the batch: 6 N^2 + 20 N."""
+    return 6.0 * N * N + 20.0 * N
+
+
+def cpu_baseline(N, tick_in, budget_s=20.0):
+    """The reference's single-thread qpOASES path on this box's host cores: the CPU restatement of
+    MPCSolver::solve with every QP solved by the reference's own vendored qpOASES (oracle/_ref),
+    cold start per QP exactly like utils.cpp:121-130.  Bounded sample of the same workload."""
+    from oracle import oracle as O
+    kind = "reference" if O.have_ref() else "port"
+    orc = O.Oracle(O.default_params(N), backend="ref" if kind == "reference" else "gi")
+    orc.solve(tick_in[:8])                       # warm-up
+    t0 = time.perf_counter(); orc.solve(tick_in[:64]); per = (time.perf_counter() - t0) / 64
+    n = int(max(64, min(len(tick_in), budget_s / max(per, 1e-6))))
+    t0 = time.perf_counter()
+    out, info = orc.solve(tick_in[:n])
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "ticks/s", "cores": 1, "kind": kind,
+            "sample": f"first {n} instances of the same batch, {dt:.1f} s, single thread, "
+                      f"{'reference vendored qpOASES 3.2 (setToMPC, nWSR=300, cold init per QP)' if kind == 'reference' else 'oracle Goldfarb-Idnani'}",
+            "ms_per_tick": 1e3 * dt / n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch-per-gpu", type=int, default=8192)
+    ap.add_argument("--horizon", type=int, default=HORIZON)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import quadruped_gait_generation_ismpc_amd as q
+    from quadruped_gait_generation_ismpc_amd import workload
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X: the hot path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+
+    N, B = args.horizon, args.batch_per_gpu
+    p = q.default_params(N=N)
+    solver = q.MPCSolver(q.reference_plan(params=p), params=p, device=local_rank)
+    tick_in = workload.make_batch(N, B, first_instance=rank * B)         # this rank's shard, no communication
+    d_in = q.to_device(tick_in, dev)
+    d_out = torch.empty((B, 80), dtype=torch.uint8, device=dev)
+    d_all = torch.empty((world * B, 80), dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        solver.solve_batch_torch(d_in, d_out)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()                   # torch's current stream == the stream the kernel is launched on
+        solver.solve_batch_torch(d_in, d_out)
+        ev[k][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    out = q.from_device(d_out, q.TICK_OUT)
+    if world > 1:
+        allout = q.from_device(d_all, q.TICK_OUT)
+        assert allout[rank * B:(rank + 1) * B].tobytes() == out.tobytes(), "all-gather misplaced this rank's shard"
+    st = out["status"]
+    frac_flight = float(((st & q.ST_FLIGHT) != 0).mean())
+    frac_infeasible = float(((st & (q.ST_X_INFEASIBLE | q.ST_Y_INFEASIBLE)) != 0).mean())
+
+    if rank == 0:
+        ticks = world * B * args.steps
+        value = ticks / elapsed
+        flops = algorithmic_flops_per_tick(N) * B
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "ISMPC QP solves/s (batch, N=100 horizon)", "value": value,
+            "unit": "ticks/s (1 tick = one MPCSolver::solve = 3 QPs: vertical + x + y)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Formulation B (MPCSolver::solve), trot plan Controller.cpp:89-97, N={N}, S=35, F=10, "
+                                   f"{B} instances/GPU (shard of BASELINE config 3: 65 536 over 8 GPUs), nominal pre-roll + perturbation (SURVEY 8d)",
+                       "horizon": N, "batch_per_gpu": B, "global_batch": world * B,
+                       "collective": "one RCCL all-gather of 80-byte output records per step" if world > 1 else "none (1 GPU)",
+                       "flight_fraction": frac_flight, "infeasible_fraction": frac_infeasible},
+            "qp_solves_per_s": 3.0 * value,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
+                         "kernel": "ismpc_tick_kernel<2>", "kernel_ms": kernel_ms,
+                         "algorithmic_flops_per_launch": flops,
+                         "note": "FP64 compute roofline (vector = matrix peak 78.6 TF); algorithmic flops 6N^2+20N per tick, "
+                                 "shared vertical factor; algorithmic HBM bytes 152 B/tick are ~1e-4 of the HBM roofline"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N, tick_in, args.cpu_budget)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

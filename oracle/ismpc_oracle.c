@@ -183,7 +183,7 @@ int orc_solve_tick(orc_solver* s, const ismpc_tick_in* in, ismpc_tick_out* out,
     /* index used at :259,329-337,381-389 */
     int idx = (int)(in->simulation_time / (dt / p->control_dt));
     info->idx = idx;
-    if (idx < 0 || idx + 2 * N > s->nmid) { out->status |= ISMPC_ST_BAD_INDEX; return 0; }
+    if (idx < 0 || idx + 2 * N > s->nmid || in->mpc_iter < 0) { out->status |= ISMPC_ST_BAD_INDEX; return 0; }
 
     /* ---- STAGE ONE, :220-278 ---- */
     int ne = (in->mpc_iter < S) ? F : (S + F - in->mpc_iter);
@@ -240,6 +240,9 @@ int orc_solve_tick(orc_solver* s, const ismpc_tick_in* in, ismpc_tick_out* out,
     info->rv[0] = s->qp(N, nC, s->H_z, f_z, Astk, lb, ub, u_z, &nwsr);
     info->nwsr[0] = nwsr;
     if (info->rv[0] != 0) out->status |= ISMPC_ST_Z_FAILED;
+    /* a working-set change in the z QP means one of the 0 <= S u <= 1e4 rows became active
+     * (equalities are in the initial working set of both backends and do not count) */
+    if (info->rv[0] == 0 && nwsr > 0) out->status |= ISMPC_ST_Z_INEQ_ACTIVE;
 
     /* :274-278 */
     out->com_pos[2] = (1.0*sz[0] + dt*sz[1]) + 0.0*u_z[0] + 0.0*g;
@@ -257,11 +260,6 @@ int orc_solve_tick(orc_solver* s, const ismpc_tick_in* in, ismpc_tick_out* out,
         zpos += s->T_z[j*2]*sz[0] + s->T_z[j*2+1]*sz[1];
         zpos += s->T_gz[j];
         lambda[j] = (g + zacc) / zpos;
-        /* inequality activity (reported, not part of the reference) */
-        if (j >= 1) {
-            double su = 0; for (int k = 0; k < N; ++k) su += s->S_z[j*N+k] * u_z[k];
-            if (su <= p->z_ineq_lo + 1e-9 || su >= p->z_ineq_hi - 1e-9) out->status |= ISMPC_ST_Z_INEQ_ACTIVE;
-        }
     }
     info->lambda0 = lambda[0];
 

@@ -1,0 +1,50 @@
+"""Builds the in-tree native libraries with hipcc for gfx950 (no JIT cache, no torch extension):
+
+  libismpc_hip.so   kernels + C ABI of include/ismpc.h   (csrc/ismpc_hip.hip, csrc/ismpc_tables.cpp)
+  libmpcsolver.so   the C++ MPCSolver drop-in class over that ABI (csrc/mpcsolver_shim.cpp)
+"""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+ROOT = os.path.dirname(PKG)
+LIB_HIP = os.path.join(PKG, "libismpc_hip.so")
+LIB_SHIM = os.path.join(PKG, "libmpcsolver.so")
+ARCH = "gfx950"
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the ISMPC kernels cannot be built")
+    return exe
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(force=False, verbose=False):
+    hip_src = [os.path.join(CSRC, "ismpc_hip.hip"), os.path.join(CSRC, "ismpc_tables.cpp")]
+    deps = hip_src + [os.path.join(CSRC, "ismpc_tables.hpp"), os.path.join(ROOT, "include", "ismpc.h")]
+    out = None if verbose else subprocess.DEVNULL
+    if force or _stale(LIB_HIP, deps):
+        subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               "-I", os.path.join(ROOT, "include")] + hip_src + ["-o", LIB_HIP], stdout=out)
+    shim_src = os.path.join(CSRC, "mpcsolver_shim.cpp")
+    if os.path.exists(shim_src):
+        sdeps = [shim_src, os.path.join(ROOT, "include", "MPCSolver.hpp"), os.path.join(ROOT, "include", "ismpc.h")]
+        if force or _stale(LIB_SHIM, sdeps):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
+                                   shim_src, "-o", LIB_SHIM, "-L", PKG, "-lismpc_hip", "-Wl,-rpath,$ORIGIN"], stdout=out)
+    return LIB_HIP
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)
+    print(LIB_HIP)

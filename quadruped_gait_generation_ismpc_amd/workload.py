@@ -1,0 +1,55 @@
+"""Synthetic batches for the ISMPC tick: nominal closed-loop pre-roll
++ per-instance perturbation.  Data generation only -- no part of the tick is computed here.
+
+The pre-roll tables (state and WalkState the solver saw at every frame of the nominal closed
+loop, Controller.cpp:297-310,346-348,503-504) are committed fixtures under tests/golden/,
+produced once by tests/golden/make_golden.py with the CPU oracle.
+"""
+import os
+
+import numpy as np
+
+from ._lib import TICK_IN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SEED = 20261003
+
+# perturbation half-widths of SURVEY.md 8d config 2
+PERTURB = dict(pos_xy=0.015, vel_xy=0.10, pos_z=0.005, vel_z=0.03)
+
+
+def load_preroll(N):
+    path = os.path.join(GOLDEN, f"preroll_N{N}.npz")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: run tests/golden/make_golden.py (needs the CPU oracle)")
+    z = np.load(path)
+    return z["tick_in"].view(TICK_IN).reshape(-1), z["frame_lo"].item(), z["frame_hi"].item()
+
+
+def make_batch(N, batch, scale=1.0, seed=SEED, first_instance=0):
+    """`batch` perturbed instances around the nominal gait at horizon N.
+    Instance i depends only on (seed, first_instance + i): shards of a larger batch are
+    reproducible on every rank without communication."""
+    table, lo, hi = load_preroll(N)
+    ids = np.arange(first_instance, first_instance + batch, dtype=np.uint64)
+    # counter-based: one Philox stream per instance id, 7 draws each
+    out = np.zeros(batch, dtype=TICK_IN)
+    u = np.empty((batch, 7))
+    # Philox is counter based; jump by instance id in blocks to stay vectorised
+    blk = 4096
+    for s in range(0, batch, blk):
+        e = min(s + blk, batch)
+        for j in range(s, e):
+            g = np.random.Generator(np.random.Philox(key=seed, counter=[0, 0, 0, int(ids[j])]))
+            u[j] = g.random(7)
+    frame = lo + np.minimum((u[:, 0] * (hi - lo + 1)).astype(np.int64), hi - lo)
+    out[:] = table[frame]
+    pm = lambda col: (2.0 * u[:, col] - 1.0)
+    out["com_pos"][:, 0] += scale * PERTURB["pos_xy"] * pm(1)
+    out["com_pos"][:, 1] += scale * PERTURB["pos_xy"] * pm(2)
+    out["com_vel"][:, 0] += scale * PERTURB["vel_xy"] * pm(3)
+    out["com_vel"][:, 1] += scale * PERTURB["vel_xy"] * pm(4)
+    out["com_pos"][:, 2] += scale * PERTURB["pos_z"] * pm(5)
+    out["com_vel"][:, 2] += scale * PERTURB["vel_z"] * pm(6)
+    return out
