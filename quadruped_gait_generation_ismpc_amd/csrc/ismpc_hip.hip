@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <new>
@@ -34,8 +35,6 @@
 namespace {
 
 constexpr int TI = 16;          // instances per workgroup = MFMA M tile
-constexpr int WAVES = 4;        // wavefronts per workgroup
-constexpr int IPW = TI / WAVES; // instances each wavefront walks through in phases A and C
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -44,32 +43,42 @@ struct DevConst {
     double dt, cdt, mass, g, h_des, half_run, half_first, q_p, q_u, q_v, z_lo, z_hi, gate, eta;
     const double *Hinv, *W, *midx, *midy, *midz, *tailx, *taily, *ftsp_t;
     const int *e_lo, *ne;
+    // affine form of the vertical stage (ismpc_tables.hpp)
+    const double *vtab, *tz, *tg, *dU, *SdU, *Wt, *SW;
+    int flat;
 };
 
-// ---- wavefront (64 lanes) primitives -------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
+// ---- wavefront (64 lanes) primitives: DPP, no LDS crossbar (ds_bpermute) on the critical path ----
+// DPP controls (GFX9 / CDNA): row_shl:n = 0x100+n, row_shr:n = 0x110+n, wave_shl:1 = 0x130,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143.  A "row" is 16 lanes.
+template <int CTRL, int ROW_MASK, bool BOUND_ZERO>
+__device__ __forceinline__ double dpp64(double old, double src)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, 0xf, BOUND_ZERO);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, 0xf, BOUND_ZERO);
+    return __hiloint2double(hi, lo);
+}
+template <int LANE>
+__device__ __forceinline__ double readlane64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), LANE), __builtin_amdgcn_readlane(__double2loint(v), LANE));
+}
+// inclusive prefix sum over lanes 0..lane
+__device__ __forceinline__ double wave_scan_up(double v)
+{
+    v += dpp64<0x111, 0xf, true>(0.0, v);
+    v += dpp64<0x112, 0xf, true>(0.0, v);
+    v += dpp64<0x114, 0xf, true>(0.0, v);
+    v += dpp64<0x118, 0xf, true>(0.0, v);
+    v += dpp64<0x142, 0xa, false>(0.0, v);      // rows 1,3 += lane 15 of the row below
+    v += dpp64<0x143, 0xc, false>(0.0, v);      // rows 2,3 += lane 31
     return v;
 }
-// sum over lanes strictly above this one
-__device__ __forceinline__ double wave_suffix_excl(double v, int lane)
-{
-    double s = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { double t = __shfl_down(s, o); if (lane + o < 64) s += t; }
-    return s - v;
-}
+// wave-uniform sum of all 64 lanes
+__device__ __forceinline__ double wave_sum(double v) { return readlane64<63>(wave_scan_up(v)); }
 // sum over lanes strictly below this one
-__device__ __forceinline__ double wave_prefix_excl(double v, int lane)
-{
-    double s = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { double t = __shfl_up(s, o); if (lane >= o) s += t; }
-    return s - v;
-}
-__device__ __forceinline__ double bcast0(double v) { return __shfl(v, 0); }
+__device__ __forceinline__ double wave_prefix_excl(double v) { return wave_scan_up(v) - v; }
+__device__ __forceinline__ double bcast0(double v) { return readlane64<0>(v); }
 
 struct M2 { double a, b, c, d; };   // [a b; c d]
 __device__ __forceinline__ M2 mul(const M2& x, const M2& y)
@@ -78,6 +87,64 @@ __device__ __forceinline__ M2 mul(const M2& x, const M2& y)
     r.a = x.a*y.a + x.b*y.c; r.b = x.a*y.b + x.b*y.d;
     r.c = x.c*y.a + x.d*y.c; r.d = x.c*y.b + x.d*y.d;
     return r;
+}
+template <int CTRL>
+__device__ __forceinline__ M2 dpp_m2_ident(const M2& y)     // out-of-range source lane -> identity
+{
+    M2 t;
+    t.a = dpp64<CTRL, 0xf, false>(1.0, y.a); t.b = dpp64<CTRL, 0xf, false>(0.0, y.b);
+    t.c = dpp64<CTRL, 0xf, false>(0.0, y.c); t.d = dpp64<CTRL, 0xf, false>(1.0, y.d);
+    return t;
+}
+template <int LANE>
+__device__ __forceinline__ M2 readlane_m2(const M2& y)
+{
+    return (M2){readlane64<LANE>(y.a), readlane64<LANE>(y.b), readlane64<LANE>(y.c), readlane64<LANE>(y.d)};
+}
+// X_lane = Y_63 Y_62 ... Y_{lane+1} (identity for lane 63); total = Y_63 ... Y_0
+__device__ __forceinline__ M2 wave_suffix_product_excl(M2 y, int lane, M2& total)
+{
+    y = mul(dpp_m2_ident<0x101>(y), y);       // row_shl:1  (lane L reads lane L+1 of its row)
+    y = mul(dpp_m2_ident<0x102>(y), y);
+    y = mul(dpp_m2_ident<0x104>(y), y);
+    y = mul(dpp_m2_ident<0x108>(y), y);
+    // first lane of each 16-lane row now holds that row's product; fold the rows above in
+    const M2 p1 = readlane_m2<16>(y), p2 = readlane_m2<32>(y), p3 = readlane_m2<48>(y);
+    const M2 m1 = mul(p3, p2), m0 = mul(m1, p1);
+    const int row = lane >> 4;
+    M2 pre = (M2){1.0, 0.0, 0.0, 1.0};
+    if (row == 2) pre = p3; else if (row == 1) pre = m1; else if (row == 0) pre = m0;
+    y = mul(pre, y);
+    total = readlane_m2<0>(y);
+    return dpp_m2_ident<0x130>(y);            // wave_shl:1 -> exclusive
+}
+
+// sinh(x)/x and (cosh(x)-1)/x^2 as functions of w = x^2.  Taylor to w^7 is exact to < 1 ulp for
+// w <= 0.25 (next term 4e-20); beyond that (lambda dt^2 > 0.25: never on a physical gait) libm.
+__device__ __forceinline__ void sinhc_coshc(double w, double& P, double& Q)
+{
+    if (__builtin_expect(w <= 0.25, 1)) {
+        P = 1.0 / 1307674368000.0;                 // 1/15!
+        P = P * w + 1.0 / 6227020800.0;            // 1/13!
+        P = P * w + 1.0 / 39916800.0;              // 1/11!
+        P = P * w + 1.0 / 362880.0;                // 1/9!
+        P = P * w + 1.0 / 5040.0;                  // 1/7!
+        P = P * w + 1.0 / 120.0;                   // 1/5!
+        P = P * w + 1.0 / 6.0;                     // 1/3!
+        P = P * w + 1.0;
+        Q = 1.0 / 20922789888000.0;                // 1/16!
+        Q = Q * w + 1.0 / 87178291200.0;           // 1/14!
+        Q = Q * w + 1.0 / 479001600.0;             // 1/12!
+        Q = Q * w + 1.0 / 3628800.0;               // 1/10!
+        Q = Q * w + 1.0 / 40320.0;                 // 1/8!
+        Q = Q * w + 1.0 / 720.0;                   // 1/6!
+        Q = Q * w + 1.0 / 24.0;                    // 1/4!
+        Q = Q * w + 0.5;
+    } else {
+        const double x = sqrt(w);
+        P = sinh(x) / x;
+        Q = (cosh(x) - 1.0) / w;
+    }
 }
 
 // Caller bookkeeping in front of solve(): Controller.cpp:297-304 (enabled) and :310.
@@ -103,11 +170,14 @@ __device__ __forceinline__ int gate_tick(const DevConst& c, const Walk& w, int& 
     return 0;
 }
 
-template <int R>
-__global__ __launch_bounds__(256)
-void ismpc_tick_kernel(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
+// R = horizon samples per lane (N <= 64 R); WAVES = wavefronts per workgroup (16 instances per
+// workgroup either way, each wavefront walks TI / WAVES of them through phases A and C).
+template <int R, int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
+void ismpc_tick_dense(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                        ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame)
 {
+    constexpr int IPW = TI / WAVES;
     extern __shared__ double smem[];                  // [TI][NPs]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -117,9 +187,12 @@ void ismpc_tick_kernel(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
     const ismpc_tick_in* in = (rollout_frame >= 0) ? state_rw : in_ro;
 
     // ---------------- phase A: f_z, MPCSolver.cpp:259 ----------------
+    // lanes hold the horizon REVERSED here (lane L <-> samples (63-L) R ..): S_bar_z' and S_bar_z_v'
+    // are sums over LATER samples, which this way are prefix sums over lanes (DPP row_shr / row_bcast).
     for (int q = 0; q < IPW; ++q) {
         const int li = wave * IPW + q;
         const int gi = inst0 + li;
+        const int nb = (63 - lane) * R;
         double f[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) f[r] = 0.0;
@@ -131,7 +204,7 @@ void ismpc_tick_kernel(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
                 double rp[R], rv[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int n = lane * R + r;
+                    const int n = nb + r;
                     if (n < N) {
                         const double k = (double)n;
                         // T_bar_z(k,:) s + T_bar_g_z(k) - h_des - mid_z ; T_bar_z_v(k,:) s + T_bar_g_z_v(k)
@@ -143,42 +216,44 @@ void ismpc_tick_kernel(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
                 double tp[R], lp = 0.0, lv = 0.0, tv[R];
 #pragma unroll
                 for (int r = R - 1; r >= 0; --r) { tv[r] = lv; lv += rv[r]; lp += rp[r]; tp[r] = lp; }
-                const double up = wave_suffix_excl(lp, lane);
-                const double uv = wave_suffix_excl(lv, lane);
+                const double up = wave_prefix_excl(lp);
+                const double uv = wave_prefix_excl(lv);
                 double vt[R], lt = 0.0;
 #pragma unroll
                 for (int r = R - 1; r >= 0; --r) { tp[r] += up; vt[r] = lt; lt += tp[r]; }
-                const double ut = wave_suffix_excl(lt, lane);
+                const double ut = wave_prefix_excl(lt);
                 const double cs = dt * dt / c.mass, cv = dt / c.mass;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int n = lane * R + r;
+                    const int n = nb + r;
                     if (n < N) f[r] = c.q_p * cs * (vt[r] + ut) + c.q_v * cv * (tv[r] + uv) - c.q_u * c.mass * c.g;
                 }
             }
         }
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const int n = lane * R + r; if (n < NP) smem[li * NPs + n] = f[r]; }
+        for (int r = 0; r < R; ++r) { const int n = nb + r; if (n < NP) smem[li * NPs + n] = f[r]; }
     }
     __syncthreads();
 
     // ---------------- phase B: U = -F Hinv on the matrix cores ----------------
     {
-        constexpr int MAXT = 4;                        // NP <= 256 -> 16 column tiles / 4 waves
+        constexpr int MAXT = (16 + WAVES - 1) / WAVES;   // NP <= 256 -> at most 16 column tiles
         const int ntiles = NP >> 4;
         d4 acc[MAXT];
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
         const int arow = lane & 15, kq = lane >> 4;
-        for (int kk = 0; kk < NP; kk += 4) {
-            const double a = smem[arow * NPs + kk + kq];                   // A[i = lane&15][k = lane>>4]
-            const double* brow = c.Hinv + (size_t)(kk + kq) * NP + arow;   // B[k = lane>>4][j = lane&15]
+        if (wave < ntiles) {
+            for (int kk = 0; kk < NP; kk += 4) {
+                const double a = smem[arow * NPs + kk + kq];                   // A[i = lane&15][k = lane>>4]
+                const double* brow = c.Hinv + (size_t)(kk + kq) * NP + arow;   // B[k = lane>>4][j = lane&15]
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const int tile = wave + t * WAVES;
-                if (tile < ntiles) {
-                    const double b = brow[tile * 16];
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                for (int t = 0; t < MAXT; ++t) {
+                    const int tile = wave + t * WAVES;
+                    if (tile < ntiles) {
+                        const double b = brow[tile * 16];
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -212,9 +287,11 @@ void ismpc_tick_kernel(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
         double u[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) u[r] = 0.0;
-        double ux_tr[R], uy_tr[R];
+        double tau[2] = {0.0, 0.0}, sgx = 1.0, sgy = 1.0, hbox = 0.0;
+        double a[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { ux_tr[r] = 0.0; uy_tr[r] = 0.0; }
+        for (int r = 0; r < R; ++r) a[r] = 0.0;
+        bool stage3 = false;
 
         if (status == 0) {
             // ---- stage 1 tail: equality correction (MPCSolver.cpp:223-243, is_running :262-263)
@@ -235,11 +312,11 @@ void ismpc_tick_kernel(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
             double ci[R], lc = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) { lc += u[r]; ci[r] = lc; }
-            const double pc = wave_prefix_excl(lc, lane);
+            const double pc = wave_prefix_excl(lc);
             double di[R], ld_ = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) { ci[r] += pc; di[r] = ld_; ld_ += ci[r]; }
-            const double pd = wave_prefix_excl(ld_, lane);
+            const double pd = wave_prefix_excl(ld_);
             const double cs = dt * dt / c.mass;
             bool viol = false;
             double lam[R];
@@ -248,12 +325,12 @@ void ismpc_tick_kernel(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
                 const int n = lane * R + r;
                 const double k = (double)n;
                 const double su = cs * (di[r] + pd);
-                if (n < N && (su < c.z_lo || su > c.z_hi)) viol = true;
+                if (n < N && (su < c.z_lo - 1e-11 * fmax(1.0, fabs(c.z_lo)) || su > c.z_hi + 1e-11 * fmax(1.0, fabs(c.z_hi)))) viol = true;   // beyond rounding
                 const double zpos = su + (z0 + (k + 1.0) * dt * zd0) - c.g * dt * dt * (0.5 * k * (k + 1.0));
                 const double zacc = (1.0 / c.mass) * u[r] - c.g;
                 lam[r] = (c.g + zacc) / zpos;                               // MPCSolver.cpp:306
             }
-            if (__any(viol)) status |= ISMPC_ST_Z_INEQ_ACTIVE;
+            if (__builtin_amdgcn_ballot_w64(viol) != 0) status |= ISMPC_ST_Z_INEQ_ACTIVE;
             uz0 = bcast0(u[0]);
             // ---- z integration, MPCSolver.cpp:274-278
             o_z = z0 + dt * zd0;
@@ -261,104 +338,106 @@ void ismpc_tick_kernel(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
             if (isnan(o_z)) { o_z = c.h_des; status |= ISMPC_ST_Z_NAN; }
             if (isnan(o_zd)) { o_zd = 0.0; status |= ISMPC_ST_Z_NAN; }
 
-            // ---- A_j, B_j per sample, MPCSolver.cpp:353-361
+            // ---- A_j, B_j per sample, MPCSolver.cpp:353-361, in the form
+            //   A = [1 + wQ, dt P; lambda dt P, 1 + wQ],  B = [-wQ, -lambda dt P],  w = lambda dt^2,
+            //   P = sinh(x)/x, Q = (cosh(x)-1)/x^2, x = sqrt(lambda) dt: no sqrt, no division, and
+            //   lambda < gate (A = [1 dt; 0 1], B = 0) is simply lambda := 0.
             M2 A[R]; double B0[R], B1[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int n = lane * R + r;
-                if (n >= N) { A[r] = (M2){1.0, 0.0, 0.0, 1.0}; B0[r] = 0.0; B1[r] = 0.0; }
-                else if (lam[r] < c.gate) { A[r] = (M2){1.0, dt, 0.0, 1.0}; B0[r] = 0.0; B1[r] = 0.0; }
-                else {
-                    const double sq = sqrt(lam[r]);
-                    const double ch = cosh(sq * dt), sh = sinh(sq * dt);
-                    A[r] = (M2){ch, sh / sq, sq * sh, ch};
-                    B0[r] = 1.0 - ch; B1[r] = -sq * sh;
-                }
+                const double le = (lam[r] < c.gate) ? 0.0 : lam[r];
+                const double dtn = (n < N) ? dt : 0.0;
+                const double wv = le * dtn * dtn;
+                double P, Q;
+                sinhc_coshc(wv, P, Q);
+                const double ch1 = wv * Q, s1 = dtn * P, s2 = le * s1;
+                A[r] = (M2){1.0 + ch1, s1, s2, 1.0 + ch1};
+                B0[r] = -ch1; B1[r] = -s2;
             }
             const double lam0 = bcast0(lam[0]);
-            const M2 A0 = (M2){bcast0(A[0].a), bcast0(A[0].b), bcast0(A[0].c), bcast0(A[0].d)};
+            const M2 A0 = readlane_m2<0>(A[0]);
             const double B00 = bcast0(B0[0]), B10 = bcast0(B1[0]);
 
             if (lam0 > c.gate) {                                           // MPCSolver.cpp:322
+                stage3 = true;
                 // ---- suffix products: X_lane = A_{N-1} ... A_{first sample of lane+1}
                 M2 Y = A[0];
 #pragma unroll
                 for (int r = 1; r < R; ++r) Y = mul(A[r], Y);
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    M2 T; T.a = __shfl_down(Y.a, o); T.b = __shfl_down(Y.b, o); T.c = __shfl_down(Y.c, o); T.d = __shfl_down(Y.d, o);
-                    if (lane + o < 64) Y = mul(T, Y);
-                }
-                M2 X; X.a = __shfl_down(Y.a, 1); X.b = __shfl_down(Y.b, 1); X.c = __shfl_down(Y.c, 1); X.d = __shfl_down(Y.d, 1);
-                if (lane == 63) X = (M2){1.0, 0.0, 0.0, 1.0};
+                M2 tot;
+                const M2 X = wave_suffix_product_excl(Y, lane, tot);
                 // row vector c_n = C_sc A_{N-1} ... A_{n+1},  C_sc = [1, 1/eta]  (MPCSolver.cpp:375-379)
                 const double ie = 1.0 / c.eta;
                 double c0 = X.a + ie * X.c, c1 = X.b + ie * X.d;
-                double a[R];
 #pragma unroll
                 for (int r = R - 1; r >= 0; --r) {
                     a[r] = c0 * B0[r] + c1 * B1[r];                        // Aeq(n) = C_sc phi_input(:,n)
                     const double n0 = c0 * A[r].a + c1 * A[r].c, n1 = c0 * A[r].b + c1 * A[r].d;
                     c0 = n0; c1 = n1;
                 }
-                const double cps0 = bcast0(c0), cps1 = bcast0(c1);           // C_sc phi_state
+                const double cps0 = tot.a + ie * tot.c, cps1 = tot.b + ie * tot.d;   // C_sc phi_state
                 // ---- box midpoints and reductions
                 const double h = (w.fc > 1) ? c.half_run : c.half_first;     // MPCSolver.cpp:328-338
-                double mx[R], my[R], aa[R];
-                double s_abs = 0.0, s_sq = 0.0, s_ax = 0.0, s_ay = 0.0;
+                hbox = h;
+                double aa[R];
+                double s_abs = 0.0, s_ax = 0.0, s_ay = 0.0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int n = lane * R + r;
-                    if (n < N) { mx[r] = c.midx[idx + n]; my[r] = c.midy[idx + n]; } else { mx[r] = 0.0; my[r] = 0.0; a[r] = 0.0; }
+                    double mx = 0.0, my = 0.0;
+                    if (n < N) { mx = c.midx[idx + n]; my = c.midy[idx + n]; } else a[r] = 0.0;
                     aa[r] = fabs(a[r]);
-                    s_abs += aa[r]; s_sq += a[r] * a[r]; s_ax += a[r] * mx[r]; s_ay += a[r] * my[r];
+                    s_abs += aa[r]; s_ax += a[r] * mx; s_ay += a[r] * my;
                 }
-                s_abs = wave_sum(s_abs); s_sq = wave_sum(s_sq); s_ax = wave_sum(s_ax); s_ay = wave_sum(s_ay);
+                s_abs = wave_sum(s_abs); s_ax = wave_sum(s_ax); s_ay = wave_sum(s_ay);
                 const double beq_x = -(cps0 * x0 + cps1 * xd0) + c.tailx[idx];   // MPCSolver.cpp:381-384
                 const double beq_y = -(cps0 * y0 + cps1 * yd0) + c.taily[idx];
-                // v = u - mid:  sum a v = bp,  |v| <= h   ->  v_n = sg * sign(a_n) * min(tau |a_n|, h)
-                const double bp[2] = { beq_x - s_ax, beq_y - s_ay };
+                // v = u - mid:  sum a v = bp,  |v| <= h   ->  v_n = sg * sign(a_n) * min(tau |a_n|, h);
+                // G(tau) = sum |a_n| min(tau |a_n|, h) is concave piecewise linear: Newton from tau = 0 is
+                // monotone and lands on the exact breakpoint interval in a handful of steps.
+                const double bpx = beq_x - s_ax, bpy = beq_y - s_ay;
+                sgx = (bpx < 0.0) ? -1.0 : 1.0; sgy = (bpy < 0.0) ? -1.0 : 1.0;
+                const double T[2] = { fabs(bpx), fabs(bpy) };
                 const double gmax = h * s_abs;
-                double tau[2]; int its[2]; bool infeas[2];
+                bool done[2]; int prev[2] = {-1, -1}, its[2] = {0, 0};
 #pragma unroll
                 for (int ax = 0; ax < 2; ++ax) {
-                    const double T = fabs(bp[ax]);
-                    infeas[ax] = T > gmax * (1.0 + 1e-12) + 1e-300;
-                    double t = 0.0; int prev = -1, it = 0;
-                    if (infeas[ax]) t = INFINITY;
-                    else {
-                        for (; it < N + 2; ++it) {
-                            double ssat = 0.0, qfree = 0.0; int cnt = 0;
+                    const bool inf = T[ax] > gmax * (1.0 + 1e-12) + 1e-300;
+                    if (inf) { status |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE); tau[ax] = INFINITY; }
+                    done[ax] = inf;
+                }
+                for (int it = 0; it < N + 2 && !(done[0] && done[1]); ++it) {
+                    double ssat[2] = {0.0, 0.0}, qfree[2] = {0.0, 0.0}; int cnt[2] = {0, 0};
 #pragma unroll
-                            for (int r = 0; r < R; ++r) {
-                                const bool sat = t * aa[r] >= h;
-                                ssat += sat ? aa[r] : 0.0;
-                                qfree += sat ? 0.0 : a[r] * a[r];
-                                cnt += __popcll(__ballot(sat));
-                            }
-                            if (cnt == prev) break;
-                            ssat = wave_sum(ssat); qfree = wave_sum(qfree);
-                            if (!(qfree > 0.0)) { t = INFINITY; break; }
-                            const double tn = (T - h * ssat) / qfree;
-                            if (!(tn > t)) break;
-                            t = tn; prev = cnt;
+                    for (int ax = 0; ax < 2; ++ax) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const bool sat = tau[ax] * aa[r] >= h;
+                            ssat[ax] += sat ? aa[r] : 0.0;
+                            qfree[ax] += sat ? 0.0 : a[r] * a[r];
+                            cnt[ax] += __popcll(__builtin_amdgcn_ballot_w64(sat));
                         }
                     }
-                    tau[ax] = t; its[ax] = it;
+#pragma unroll
+                    for (int ax = 0; ax < 2; ++ax) {
+                        if (done[ax]) continue;
+                        if (cnt[ax] == prev[ax]) { done[ax] = true; continue; }
+                        const double ss = wave_sum(ssat[ax]), qf = wave_sum(qfree[ax]);
+                        ++its[ax];
+                        if (!(qf > 0.0)) { tau[ax] = INFINITY; done[ax] = true; continue; }
+                        const double tn = (T[ax] - h * ss) / qf;
+                        if (!(tn > tau[ax])) { done[ax] = true; continue; }
+                        tau[ax] = tn; prev[ax] = cnt[ax];
+                    }
                 }
                 itx = its[0]; ity = its[1];
-                if (infeas[0]) status |= ISMPC_ST_X_INFEASIBLE;
-                if (infeas[1]) status |= ISMPC_ST_Y_INFEASIBLE;
-                const double sgx = (bp[0] < 0.0) ? -1.0 : 1.0, sgy = (bp[1] < 0.0) ? -1.0 : 1.0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const double sa = (a[r] < 0.0) ? -1.0 : 1.0;
-                    const double vx = (aa[r] > 0.0) ? fmin(tau[0] * aa[r], h) : 0.0;
-                    const double vy = (aa[r] > 0.0) ? fmin(tau[1] * aa[r], h) : 0.0;
-                    ux_tr[r] = mx[r] + sgx * sa * vx;
-                    uy_tr[r] = my[r] + sgy * sa * vy;
+                {   // first decision variables (lane 0 holds sample 0)
+                    const double a0 = bcast0(a[0]), aa0 = fabs(a0), sa0 = (a0 < 0.0) ? -1.0 : 1.0;
+                    const double m0x = c.midx[idx], m0y = c.midy[idx];
+                    ux0 = m0x + sgx * sa0 * ((aa0 > 0.0) ? fmin(tau[0] * aa0, h) : 0.0);
+                    uy0 = m0y + sgy * sa0 * ((aa0 > 0.0) ? fmin(tau[1] * aa0, h) : 0.0);
                 }
-                ux0 = bcast0(ux_tr[0]); uy0 = bcast0(uy_tr[0]);
             } else {
                 status |= ISMPC_ST_FLIGHT;
             }
@@ -387,7 +466,15 @@ void ismpc_tick_kernel(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int n = lane * R + r;
-                if (n < N) { dst[n] = u[r]; dst[N + n] = ux_tr[r]; dst[2 * N + n] = uy_tr[r]; }
+                if (n < N) {
+                    double vx = 0.0, vy = 0.0;
+                    if (stage3) {
+                        const double aa = fabs(a[r]), sa = (a[r] < 0.0) ? -1.0 : 1.0;
+                        vx = c.midx[idx + n] + sgx * sa * ((aa > 0.0) ? fmin(tau[0] * aa, hbox) : 0.0);
+                        vy = c.midy[idx + n] + sgy * sa * ((aa > 0.0) ? fmin(tau[1] * aa, hbox) : 0.0);
+                    }
+                    dst[n] = u[r]; dst[N + n] = vx; dst[2 * N + n] = vy;
+                }
             }
         }
         // ---- closed loop: feed back (Controller.cpp:346-348) and advance counters (:503-504)
@@ -401,6 +488,286 @@ void ismpc_tick_kernel(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
             st->mpc_iter = (int)floor(ctl * c.cdt / c.dt);
             st->footstep_counter = w.fc;
         }
+    }
+}
+
+// ======================================================================================
+// Fast path: one wavefront = one instance, no LDS, no barrier.
+// The vertical QP (MPCSolver.cpp:220-278) is evaluated from the affine tables (the dense solve
+// happened once at ismpc_create); what is left per tick is the nonlinear part: lambda_j, the
+// 2x2 suffix scan, and the two exact knapsack solves.
+// ======================================================================================
+template <int CTRL>
+__device__ __forceinline__ double dpp64z(double src)        // DPP move, out-of-range source lanes read 0
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// y <- T y for T = I + Tm taken from another lane (Tm = 0 where that lane does not exist)
+template <int CTRL>
+__device__ __forceinline__ void scan_step(M2& y)
+{
+    const double ta = dpp64z<CTRL>(y.a - 1.0), tb = dpp64z<CTRL>(y.b), tc = dpp64z<CTRL>(y.c), td = dpp64z<CTRL>(y.d - 1.0);
+    M2 r;
+    r.a = fma(ta, y.a, fma(tb, y.c, y.a)); r.b = fma(ta, y.b, fma(tb, y.d, y.b));
+    r.c = fma(tc, y.a, fma(td, y.c, y.c)); r.d = fma(tc, y.b, fma(td, y.d, y.d));
+    y = r;
+}
+template <int R> __device__ __forceinline__ void loadR(const double* p, double (&v)[R])
+{
+    if constexpr (R == 2) { const double2 t = *reinterpret_cast<const double2*>(p); v[0] = t.x; v[1] = t.y; }
+    else if constexpr (R == 4) { const double2 t = *reinterpret_cast<const double2*>(p), q = *reinterpret_cast<const double2*>(p + 2); v[0] = t.x; v[1] = t.y; v[2] = q.x; v[3] = q.y; }
+    else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = p[r];
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256)
+void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
+                       ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame)
+{
+    constexpr int NT = ismpc::Tables::NT;
+    const int lane = threadIdx.x & 63;
+    const int gi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (gi >= batch) return;
+    const int N = c.N;
+    const double dt = c.dt;
+    const ismpc_tick_in* rec = ((rollout_frame >= 0) ? state_rw : in_ro) + gi;
+    const Walk w = load_walk(c, rec, rollout_frame);
+    const double x0 = rec->com_pos[0], y0 = rec->com_pos[1], z0 = rec->com_pos[2];
+    const double xd0 = rec->com_vel[0], yd0 = rec->com_vel[1], zd0 = rec->com_vel[2];
+    int idx;
+    int status = gate_tick(c, w, idx);
+    double o_x = x0, o_y = y0, o_z = z0, o_xd = xd0, o_yd = yd0, o_zd = zd0;
+    double uz0 = 0.0, ux0 = 0.0, uy0 = 0.0;
+    int itx = 0, ity = 0;
+    const int n0 = lane * R;                          // this lane owns samples n0 .. n0+R-1 (tables are zero past N)
+    double u[R], a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { u[r] = 0.0; a[r] = 0.0; }
+    double tau0 = 0.0, tau1 = 0.0, sgx = 1.0, sgy = 1.0, hbox = 0.0;
+    bool stage3 = false;
+
+    if (status == 0) {
+        // ---- vertical stage from the affine tables; pattern = which u_i = 0 rows are present
+        // (MPCSolver.cpp:223-243, is_running :262-263)
+        const int pat = (w.fc > 1 && w.mpc < c.npat) ? w.mpc : c.npat;
+        const double* T = c.vtab + (size_t)pat * 6 * NT + n0;
+        double t0[R], t1[R], t2[R], su[R], tz[R], tg[R];
+        loadR<R>(T, t0); loadR<R>(T + NT, t1); loadR<R>(T + 2 * NT, t2);
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = fma(zd0, t2[r], fma(z0, t1[r], t0[r]));
+        loadR<R>(T + 3 * NT, t0); loadR<R>(T + 4 * NT, t1); loadR<R>(T + 5 * NT, t2);
+#pragma unroll
+        for (int r = 0; r < R; ++r) su[r] = fma(zd0, t2[r], fma(z0, t1[r], t0[r]));
+        loadR<R>(c.tz + n0, tz); loadR<R>(c.tg + n0, tg);
+        double mx[R], my[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {                  // issued early: used after the scan
+            const int n = n0 + r;
+            mx[r] = (n < N) ? c.midx[idx + n] : 0.0; my[r] = (n < N) ? c.midy[idx + n] : 0.0;
+        }
+        const double tailx = c.tailx[idx], taily = c.taily[idx];
+        if (!c.flat) {                                  // plans with mid_z != 0 (MPCSolver.cpp:259)
+            double du[R], ds[R];
+            loadR<R>(c.dU + (size_t)idx * NT + n0, du); loadR<R>(c.SdU + (size_t)idx * NT + n0, ds);
+            int elo = 0, ne = 0;
+            if (pat < c.npat) { elo = c.e_lo[pat]; ne = c.ne[pat]; }
+            for (int e = 0; e < ne; ++e) {
+                const double ue = c.dU[(size_t)idx * NT + elo + e];
+                double wv[R], sv[R];
+                loadR<R>(c.Wt + ((size_t)pat * c.Fmax + e) * NT + n0, wv); loadR<R>(c.SW + ((size_t)pat * c.Fmax + e) * NT + n0, sv);
+#pragma unroll
+                for (int r = 0; r < R; ++r) { du[r] -= wv[r] * ue; ds[r] -= sv[r] * ue; }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int n = n0 + r;
+                u[r] += du[r]; su[r] += ds[r];
+                if (n >= elo && n < elo + ne) u[r] = 0.0;
+            }
+        }
+        bool viol = false;
+        double lam[R];
+        const double zlo_t = c.z_lo - 1e-11 * fmax(1.0, fabs(c.z_lo)), zhi_t = c.z_hi + 1e-11 * fmax(1.0, fabs(c.z_hi));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = n0 + r;
+            viol = viol || (n < N && (su[r] < zlo_t || su[r] > zhi_t));         // MPCSolver.cpp:158-160, beyond rounding
+            const double zpos = su[r] + fma(tz[r], zd0, z0) + tg[r];            // S u + T_bar_z s + T_bar_g_z
+            const double zacc = (1.0 / c.mass) * u[r] - c.g;
+            lam[r] = (c.g + zacc) / zpos;                                       // MPCSolver.cpp:306
+        }
+        if (__builtin_amdgcn_ballot_w64(viol) != 0) status |= ISMPC_ST_Z_INEQ_ACTIVE;
+        uz0 = bcast0(u[0]);
+        o_z = z0 + dt * zd0;                                                    // MPCSolver.cpp:274-278
+        o_zd = zd0 + (dt / c.mass) * uz0 - dt * c.g;
+        if (isnan(o_z)) { o_z = c.h_des; status |= ISMPC_ST_Z_NAN; }
+        if (isnan(o_zd)) { o_zd = 0.0; status |= ISMPC_ST_Z_NAN; }
+
+        // ---- A_j, B_j (MPCSolver.cpp:353-361): A = [1+wQ, dt P; lam dt P, 1+wQ], B = [-wQ, -lam dt P]
+        double ch1[R], s1[R], s2[R];
+        bool big = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = n0 + r;
+            const double le = (lam[r] < c.gate) ? 0.0 : lam[r];
+            const double dtn = (n < N) ? dt : 0.0;
+            const double wv = le * dtn * dtn;
+            big = big || (wv > 0.25);
+            double P = 1.0 / 1307674368000.0, Q = 1.0 / 20922789888000.0;
+            P = fma(P, wv, 1.0 / 6227020800.0);  Q = fma(Q, wv, 1.0 / 87178291200.0);
+            P = fma(P, wv, 1.0 / 39916800.0);    Q = fma(Q, wv, 1.0 / 479001600.0);
+            P = fma(P, wv, 1.0 / 362880.0);      Q = fma(Q, wv, 1.0 / 3628800.0);
+            P = fma(P, wv, 1.0 / 5040.0);        Q = fma(Q, wv, 1.0 / 40320.0);
+            P = fma(P, wv, 1.0 / 120.0);         Q = fma(Q, wv, 1.0 / 720.0);
+            P = fma(P, wv, 1.0 / 6.0);           Q = fma(Q, wv, 1.0 / 24.0);
+            P = fma(P, wv, 1.0);                 Q = fma(Q, wv, 0.5);
+            ch1[r] = wv * Q; s1[r] = dtn * P; s2[r] = le * s1[r];
+        }
+        if (__builtin_amdgcn_ballot_w64(big) != 0) {      // lambda dt^2 > 1/4: off any physical gait; libm, wave-uniform
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int n = n0 + r;
+                const double le = (lam[r] < c.gate) ? 0.0 : lam[r];
+                const double dtn = (n < N) ? dt : 0.0;
+                const double wv = le * dtn * dtn;
+                if (wv > 0.25) { const double x = sqrt(wv); ch1[r] = cosh(x) - 1.0; s1[r] = dtn * (sinh(x) / x); s2[r] = le * s1[r]; }
+            }
+        }
+        const double lam0 = bcast0(lam[0]);
+        const double A0a = 1.0 + bcast0(ch1[0]), A0b = bcast0(s1[0]), A0c = bcast0(s2[0]);
+
+        if (lam0 > c.gate) {                                                    // MPCSolver.cpp:322
+            stage3 = true;
+            // ---- inclusive suffix product over lanes: Y_L = A(block 63) ... A(block L), row by row
+            M2 Y = (M2){1.0 + ch1[0], s1[0], s2[0], 1.0 + ch1[0]};
+#pragma unroll
+            for (int r = 1; r < R; ++r) Y = mul((M2){1.0 + ch1[r], s1[r], s2[r], 1.0 + ch1[r]}, Y);
+            scan_step<0x101>(Y); scan_step<0x102>(Y); scan_step<0x104>(Y); scan_step<0x108>(Y);   // row_shl 1,2,4,8
+            // g_row = C_sc P_3 .. P_{row+1}  (P_r = product of row r = Y at its first lane), C_sc = [1, 1/eta]
+            const double ie = 1.0 / c.eta;
+            const M2 p1 = readlane_m2<16>(Y), p2 = readlane_m2<32>(Y), p3 = readlane_m2<48>(Y);
+            const double g2a = fma(ie, p3.c, p3.a), g2b = fma(ie, p3.d, p3.b);
+            const double g1a = fma(g2b, p2.c, g2a * p2.a), g1b = fma(g2b, p2.d, g2a * p2.b);
+            const double g0a = fma(g1b, p1.c, g1a * p1.a), g0b = fma(g1b, p1.d, g1a * p1.b);
+            const int row = lane >> 4;
+            const double ga = row == 3 ? 1.0 : (row == 2 ? g2a : (row == 1 ? g1a : g0a));
+            const double gb = row == 3 ? ie  : (row == 2 ? g2b : (row == 1 ? g1b : g0b));
+            // cv_L = C_sc (suffix product from the first sample of lane L) ; the lane needs it one lane up
+            const double cva = fma(gb, Y.c, ga * Y.a), cvb = fma(gb, Y.d, ga * Y.b);
+            const double cps0 = readlane64<0>(cva), cps1 = readlane64<0>(cvb);  // C_sc phi_state
+            double c0 = dpp64<0x130, 0xf, false>(1.0, cva), c1 = dpp64<0x130, 0xf, false>(ie, cvb);   // wave_shl:1
+            // ---- Aeq(n) = C_sc phi_input(:,n) = c_n B_n, walking the lane's samples backwards
+#pragma unroll
+            for (int r = R - 1; r >= 0; --r) {
+                a[r] = -(c0 * ch1[r] + c1 * s2[r]);
+                const double k0 = fma(c0, ch1[r], fma(c1, s2[r], c0)), k1 = fma(c1, ch1[r], fma(c0, s1[r], c1));
+                c0 = k0; c1 = k1;
+            }
+            const double h = (w.fc > 1) ? c.half_run : c.half_first;            // MPCSolver.cpp:328-338
+            hbox = h;
+            double q0 = 0.0, s_ax = 0.0, s_ay = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { q0 = fma(a[r], a[r], q0); s_ax = fma(a[r], mx[r], s_ax); s_ay = fma(a[r], my[r], s_ay); }
+            q0 = wave_sum(q0); s_ax = wave_sum(s_ax); s_ay = wave_sum(s_ay);
+            const double bpx = (tailx - fma(cps0, x0, cps1 * xd0)) - s_ax;      // beq - a'mid, MPCSolver.cpp:381-384
+            const double bpy = (taily - fma(cps0, y0, cps1 * yd0)) - s_ay;
+            sgx = (bpx < 0.0) ? -1.0 : 1.0; sgy = (bpy < 0.0) ? -1.0 : 1.0;
+            // min 1/2|v|^2, a'v = bp, |v| <= h  ->  v_n = sg sign(a_n) min(tau |a_n|, h): Newton on the concave
+            // piecewise-linear G(tau) = sum |a_n| min(tau |a_n|, h) from tau = 0 (first step: tau = |bp| / sum a^2)
+            const double T[2] = { fabs(bpx), fabs(bpy) };
+            double tau[2] = { T[0] / q0, T[1] / q0 };
+            int its[2] = {1, 1};
+            double aa[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) aa[r] = fabs(a[r]);
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) {
+                if (!(q0 > 0.0)) {                                               // no sample can move the ZMP
+                    tau[ax] = (T[ax] > 0.0) ? INFINITY : 0.0;
+                    if (T[ax] > 1e-300) status |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
+                }
+                int prev = 0;
+                for (int it = 0; it < N + 2; ++it) {
+                    int cnt = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) cnt += __popcll(__builtin_amdgcn_ballot_w64(tau[ax] * aa[r] >= h));
+                    if (cnt == prev) break;                                      // active set unchanged: exact
+                    double ssat = 0.0, qfree = 0.0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { const bool sat = tau[ax] * aa[r] >= h; ssat += sat ? aa[r] : 0.0; qfree += sat ? 0.0 : a[r] * a[r]; }
+                    ssat = wave_sum(ssat); qfree = wave_sum(qfree);
+                    ++its[ax];
+                    const double rem = T[ax] - h * ssat;
+                    if (!(qfree > 0.0)) {                                        // everything saturated
+                        if (rem > h * ssat * 1e-12 + 1e-300) status |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
+                        tau[ax] = INFINITY; break;
+                    }
+                    const double tn = rem / qfree;
+                    if (!(tn > tau[ax])) break;
+                    tau[ax] = tn; prev = cnt;
+                }
+            }
+            tau0 = tau[0]; tau1 = tau[1]; itx = its[0]; ity = its[1];
+            {   // first decision variables (lane 0 holds sample 0)
+                const double a0 = bcast0(a[0]), aa0 = fabs(a0), sa0 = (a0 < 0.0) ? -1.0 : 1.0;
+                const double m0x = bcast0(mx[0]), m0y = bcast0(my[0]);
+                ux0 = m0x + sgx * sa0 * ((aa0 > 0.0) ? fmin(tau0 * aa0, h) : 0.0);
+                uy0 = m0y + sgy * sa0 * ((aa0 > 0.0) ? fmin(tau1 * aa0, h) : 0.0);
+            }
+        } else {
+            status |= ISMPC_ST_FLIGHT;
+        }
+        // ---- integration with A(lambda_0), B(lambda_0), MPCSolver.cpp:406-422
+        o_x  = (A0a * x0 + A0b * xd0) + (1.0 - A0a) * ux0;
+        o_xd = (A0c * x0 + A0a * xd0) - A0c * ux0;
+        o_y  = (A0a * y0 + A0b * yd0) + (1.0 - A0a) * uy0;
+        o_yd = (A0c * y0 + A0a * yd0) - A0c * uy0;
+    }
+
+    // ---- 80-byte output record: lanes 0..9 store one 8-byte word each
+    {
+        double word = 0.0;
+        const long long packed = (long long)(unsigned)status | ((long long)(unsigned)((itx & 255) | ((ity & 255) << 8)) << 32);
+        switch (lane) {
+            case 0: word = o_x; break;  case 1: word = o_y; break;  case 2: word = o_z; break;
+            case 3: word = o_xd; break; case 4: word = o_yd; break; case 5: word = o_zd; break;
+            case 6: word = uz0; break;  case 7: word = ux0; break;  case 8: word = uy0; break;
+            case 9: word = __longlong_as_double(packed); break;
+            default: break;
+        }
+        if (out && lane < 10) reinterpret_cast<double*>(out + gi)[lane] = word;
+    }
+    if (u_traj) {
+        double* dst = u_traj + (size_t)gi * 3 * N;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = n0 + r;
+            if (n < N) {
+                double vx = 0.0, vy = 0.0;
+                if (stage3) {
+                    const double aa = fabs(a[r]), sa = (a[r] < 0.0) ? -1.0 : 1.0;
+                    vx = c.midx[idx + n] + sgx * sa * ((aa > 0.0) ? fmin(tau0 * aa, hbox) : 0.0);
+                    vy = c.midy[idx + n] + sgy * sa * ((aa > 0.0) ? fmin(tau1 * aa, hbox) : 0.0);
+                }
+                dst[n] = u[r]; dst[N + n] = vx; dst[2 * N + n] = vy;
+            }
+        }
+    }
+    // ---- closed loop: feed back (Controller.cpp:346-348) and advance counters (:503-504)
+    if (rollout_frame >= 0 && lane == 0) {
+        ismpc_tick_in* st = state_rw + gi;
+        st->com_pos[0] = o_x; st->com_pos[1] = o_y; st->com_pos[2] = o_z;
+        st->com_vel[0] = o_xd; st->com_vel[1] = o_yd; st->com_vel[2] = o_zd;
+        st->simulation_time = w.sim;
+        const int ctl = w.ctl + 1;
+        st->control_iter = ctl;
+        st->mpc_iter = (int)floor(ctl * c.cdt / c.dt);
+        st->footstep_counter = w.fc;
     }
 }
 
@@ -422,6 +789,8 @@ struct ismpc_handle {
     hipStream_t own_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false; bool timed_pending = false; double last_ms = 0.0;
+    int force_waves = 0;      // dense path: 4, 8 or 16 wavefronts per workgroup (0 = 16)
+    bool dense_path = false;  // true: per-tick MFMA solve (ismpc_tick_dense); false: affine tables (ismpc_tick_affine)
 };
 
 namespace {
@@ -443,15 +812,34 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
 {
     if (batch <= 0) return ISMPC_OK;
     const int R = (h->c.N + 63) / 64;
-    const dim3 grid((batch + TI - 1) / TI), block(64 * WAVES);
+    if (!h->dense_path) {
+        // fast path: wavefront per instance, 4 per workgroup
+        const dim3 grid((batch + 3) / 4), block(256);
+        switch (R) {
+            case 1: hipLaunchKernelGGL(ismpc_tick_affine<1>, grid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
+            case 2: hipLaunchKernelGGL(ismpc_tick_affine<2>, grid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
+            case 3: hipLaunchKernelGGL(ismpc_tick_affine<3>, grid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
+            case 4: hipLaunchKernelGGL(ismpc_tick_affine<4>, grid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
+            default: return fail(ISMPC_E_UNSUPPORTED, "horizon N > 256");
+        }
+        HIP_TRY(hipGetLastError());
+        return ISMPC_OK;
+    }
+    // dense path (kept for A/B and as the per-tick MFMA formulation): 16 instances per workgroup
+    const dim3 grid((batch + TI - 1) / TI);
     const size_t lds = (size_t)TI * h->c.NPs * sizeof(double);
+    const int waves = h->force_waves ? h->force_waves : 16;
+#define ISMPC_LAUNCH(RR, WW) hipLaunchKernelGGL((ismpc_tick_dense<RR, WW>), grid, dim3(64 * WW), lds, s, h->c, in, state, out, u_traj, batch, rollout_frame)
+#define ISMPC_LAUNCH_R(RR) do { if (waves == 16) ISMPC_LAUNCH(RR, 16); else if (waves == 8) ISMPC_LAUNCH(RR, 8); else ISMPC_LAUNCH(RR, 4); } while (0)
     switch (R) {
-        case 1: hipLaunchKernelGGL(ismpc_tick_kernel<1>, grid, block, lds, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
-        case 2: hipLaunchKernelGGL(ismpc_tick_kernel<2>, grid, block, lds, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
-        case 3: hipLaunchKernelGGL(ismpc_tick_kernel<3>, grid, block, lds, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
-        case 4: hipLaunchKernelGGL(ismpc_tick_kernel<4>, grid, block, lds, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
+        case 1: ISMPC_LAUNCH_R(1); break;
+        case 2: ISMPC_LAUNCH_R(2); break;
+        case 3: ISMPC_LAUNCH_R(3); break;
+        case 4: ISMPC_LAUNCH_R(4); break;
         default: return fail(ISMPC_E_UNSUPPORTED, "horizon N > 256");
     }
+#undef ISMPC_LAUNCH_R
+#undef ISMPC_LAUNCH
     HIP_TRY(hipGetLastError());
     return ISMPC_OK;
 }
@@ -494,6 +882,11 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     int rc = ismpc::build_tables(*params, ftsp, rows, h->t, err);
     if (rc != ISMPC_OK) { delete h; return fail(rc, err); }
     h->device = device;
+    if (const char* fw = std::getenv("ISMPC_WAVES")) {            // tuning knob: wavefronts per workgroup
+        const int v = std::atoi(fw);
+        if (v == 4 || v == 8 || v == 16) h->force_waves = v;
+    }
+    if (const char* pth = std::getenv("ISMPC_PATH")) h->dense_path = std::strcmp(pth, "dense") == 0;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete h; return fail(ISMPC_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
     const ismpc::Tables& t = h->t;
@@ -514,6 +907,14 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     if (rc == ISMPC_OK) rc = upload(h, t.ftsp_t, &c.ftsp_t);
     if (rc == ISMPC_OK) rc = upload(h, t.e_lo, &c.e_lo);
     if (rc == ISMPC_OK) rc = upload(h, t.ne, &c.ne);
+    if (rc == ISMPC_OK) rc = upload(h, t.vtab, &c.vtab);
+    if (rc == ISMPC_OK) rc = upload(h, t.tz, &c.tz);
+    if (rc == ISMPC_OK) rc = upload(h, t.tg, &c.tg);
+    if (rc == ISMPC_OK) rc = upload(h, t.dU, &c.dU);
+    if (rc == ISMPC_OK) rc = upload(h, t.SdU, &c.SdU);
+    if (rc == ISMPC_OK) rc = upload(h, t.Wt, &c.Wt);
+    if (rc == ISMPC_OK) rc = upload(h, t.SW, &c.SW);
+    c.flat = t.flat ? 1 : 0;
     if (rc != ISMPC_OK) { ismpc_destroy(h); return rc; }
     if (hipStreamCreate(&h->own_stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
         hipEventCreate(&h->ev1) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_NO_DEVICE, "stream/event creation failed"); }

@@ -96,6 +96,7 @@ int build_tables(const ismpc_params& p, const double* ftsp, int rows, Tables& t,
     // depends only on mpcIter.  Correction  u = u_unc - W (u_unc)_E,  W = Hinv[:,E] (Hinv[E,E])^-1.
     t.e_lo.assign(t.npat, 0); t.ne.assign(t.npat, 0);
     t.W.assign((size_t)t.npat * t.Fmax * t.NP, 0.0);
+    std::vector<ld> Wld((size_t)t.npat * t.Fmax * N, 0);     // long-double copy for the affine tables below
     for (int it = 0; it < t.npat; ++it) {
         // the reference fills Aeq_z inside `for (i = 0; i < N; i++)` (:231): row i-S, column i-mpcIter for
         // S <= i < min(S+F, N) while mpcIter < S, else column i for i < min(S+F-mpcIter, N)
@@ -115,6 +116,7 @@ int build_tables(const ismpc_params& p, const double* ftsp, int rows, Tables& t,
                 ld s = 0;
                 for (int a = 0; a < cnt; ++a) s += Hinv[(size_t)n*N + (lo+a)] * Gi[(size_t)a*cnt+e];
                 t.W[((size_t)it*t.Fmax + e)*t.NP + n] = (double)s;
+                Wld[((size_t)it*t.Fmax + e)*N + n] = s;
             }
     }
 
@@ -141,6 +143,86 @@ int build_tables(const ismpc_params& p, const double* ftsp, int rows, Tables& t,
             sx += wgt * t.midx[idx+N+i]; sy += wgt * t.midy[idx+N+i];
         }
         t.tailx[idx] = sx; t.taily[idx] = sy;
+    }
+
+    // ---- affine tables of the vertical stage (see ismpc_tables.hpp) ----
+    const int NT = Tables::NT;
+    auto apply_St = [&](const std::vector<ld>& r, std::vector<ld>& o, bool vel) {   // S_bar_z' r  or  S_bar_z_v' r
+        o.assign(N, 0);
+        if (vel) { ld acc = 0; for (int i = N - 1; i >= 0; --i) { o[i] = cv * acc; acc += r[i]; } }
+        else { ld t1 = 0, t2 = 0; for (int i = N - 1; i >= 0; --i) { o[i] = cs * t2; t1 += r[i]; t2 += t1; } }
+    };
+    auto apply_S = [&](const std::vector<ld>& u, std::vector<ld>& o) {              // S_bar_z u
+        o.assign(N, 0); ld c1 = 0, c2 = 0;
+        for (int k = 0; k < N; ++k) { o[k] = cs * c2; c1 += u[k]; c2 += c1; }
+    };
+    auto apply_Hinv = [&](const std::vector<ld>& f, std::vector<ld>& o) {
+        o.assign(N, 0);
+        for (int i = 0; i < N; ++i) { ld s = 0; for (int j = 0; j < N; ++j) s += Hinv[(size_t)i*N+j] * f[j]; o[i] = s; }
+    };
+    // f = f0 + z fa + zdot fb - q_p S' mid_z(window)      (MPCSolver.cpp:259)
+    std::vector<ld> one(N, 1), tvec(N), tgv(N), tgz(N), tmp, tmp2, f0(N), fa(N), fb(N);
+    t.tz.assign(NT, 0.0); t.tg.assign(NT, 0.0);
+    for (int k = 0; k < N; ++k) {
+        tvec[k] = (ld)(k + 1) * dt;                               // T_bar_z(k,1)
+        tgz[k] = -(ld)p.g * dt * dt * ((ld)k * (ld)(k + 1) / 2);  // T_bar_g_z(k)
+        tgv[k] = -(ld)p.g * dt * (ld)k;                           // T_bar_g_z_v(k)
+        t.tz[k] = (double)tvec[k]; t.tg[k] = (double)tgz[k];
+    }
+    {
+        std::vector<ld> r0(N);
+        for (int k = 0; k < N; ++k) r0[k] = tgz[k] - (ld)p.h_des;
+        apply_St(r0, tmp, false); apply_St(tgv, tmp2, true);
+        for (int i = 0; i < N; ++i) f0[i] = (ld)p.q_p * tmp[i] + (ld)p.q_v * tmp2[i] - (ld)p.q_u * m * (ld)p.g;
+        apply_St(one, tmp, false);
+        for (int i = 0; i < N; ++i) fa[i] = (ld)p.q_p * tmp[i];
+        apply_St(tvec, tmp, false); apply_St(one, tmp2, true);
+        for (int i = 0; i < N; ++i) fb[i] = (ld)p.q_p * tmp[i] + (ld)p.q_v * tmp2[i];
+    }
+    std::vector<ld> h0, ha, hb;
+    apply_Hinv(f0, h0); apply_Hinv(fa, ha); apply_Hinv(fb, hb);
+    t.vtab.assign((size_t)(t.npat + 1) * 6 * NT, 0.0);
+    for (int pat = 0; pat <= t.npat; ++pat) {
+        const int lo = pat < t.npat ? t.e_lo[pat] : 0, cnt = pat < t.npat ? t.ne[pat] : 0;
+        const std::vector<ld>* src[3] = { &h0, &ha, &hb };
+        for (int b = 0; b < 3; ++b) {
+            std::vector<ld> u(N), su;
+            for (int n = 0; n < N; ++n) {
+                ld v = (*src[b])[n];
+                for (int e = 0; e < cnt; ++e) v -= Wld[((size_t)pat*t.Fmax + e)*N + n] * (*src[b])[lo + e];
+                u[n] = -v;                                          // u = -P_p f
+            }
+            for (int e = 0; e < cnt; ++e) u[lo + e] = 0;            // exactly zero on the equality samples
+            apply_S(u, su);
+            for (int n = 0; n < N; ++n) {
+                t.vtab[((size_t)pat*6 + b)*NT + n] = (double)u[n];
+                t.vtab[((size_t)pat*6 + 3 + b)*NT + n] = (double)su[n];
+            }
+        }
+    }
+    t.flat = true;
+    for (int i = 0; i < t.nmid; ++i) if (t.midz[i] != 0.0) { t.flat = false; break; }
+    if (!t.flat) {
+        t.dU.assign((size_t)t.nmid * NT, 0.0); t.SdU.assign((size_t)t.nmid * NT, 0.0);
+        std::vector<ld> win(N), g, du, sdu;
+        for (int idx = 0; idx + 2*N <= t.nmid; ++idx) {
+            bool any = false;
+            for (int k = 0; k < N; ++k) { win[k] = t.midz[idx + k]; any = any || win[k] != 0; }
+            if (!any) continue;
+            apply_St(win, g, false);
+            for (int i = 0; i < N; ++i) g[i] *= (ld)p.q_p;          // f -= g  ->  u_unc += Hinv g
+            apply_Hinv(g, du); apply_S(du, sdu);
+            for (int n = 0; n < N; ++n) { t.dU[(size_t)idx*NT + n] = (double)du[n]; t.SdU[(size_t)idx*NT + n] = (double)sdu[n]; }
+        }
+        t.Wt.assign((size_t)t.npat * t.Fmax * NT, 0.0); t.SW.assign((size_t)t.npat * t.Fmax * NT, 0.0);
+        std::vector<ld> col(N), scol;
+        for (int it = 0; it < t.npat; ++it)
+            for (int e = 0; e < t.ne[it]; ++e) {
+                for (int n = 0; n < N; ++n) col[n] = Wld[((size_t)it*t.Fmax + e)*N + n];
+                // on the equality samples the corrected u is forced to 0 by the kernel; elsewhere W applies
+                apply_S(col, scol);
+                for (int n = 0; n < N; ++n) { t.Wt[((size_t)it*t.Fmax + e)*NT + n] = (double)col[n]; t.SW[((size_t)it*t.Fmax + e)*NT + n] = (double)scol[n]; }
+            }
     }
     return ISMPC_OK;
 }

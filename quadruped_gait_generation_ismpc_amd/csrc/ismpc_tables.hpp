@@ -26,6 +26,21 @@ struct Tables {
     std::vector<double> midx, midy, midz;   // nmid each: ftsp_midpoint columns, MPCSolver.cpp:167-180
     std::vector<double> tailx, taily;       // nmid each: eta*dt*sum_i exp(-dt*eta*i)*mid[idx+N+i], MPCSolver.cpp:183-184,381-383
     std::vector<double> ftsp_t;             // rows: ftsp_and_timings(:,3), Controller.cpp:96
+
+    // ---- "affine" form of the vertical stage (what the fast kernel reads) ----
+    // With the inequality rows inactive, the z-QP (MPCSolver.cpp:258-269) is an equality constrained
+    // least squares whose solution is AFFINE in the state (z, zdot) and in the mid_z window:
+    //     u      = U0_p  + z Ua_p  + zdot Ub_p   [+ dU(idx)  - W_p  (dU(idx))_E]
+    //     S_z u  = SU0_p + z SUa_p + zdot SUb_p  [+ SdU(idx) - SW_p (dU(idx))_E]
+    // p = equality pattern (mpcIter, or npat = "no equalities": footstepCounter <= 1 or mpcIter >= S+F).
+    // The dense N x N contraction with Hinv therefore happens here, once, not per tick.
+    static constexpr int NT = 256;          // padded horizon of every table row
+    std::vector<double> vtab;               // (npat+1) x 6 x NT : U0,Ua,Ub,SU0,SUa,SUb ; zero for n >= N
+    std::vector<double> tz, tg;             // NT each: T_bar_z(n,1) = (n+1) dt ; T_bar_g_z(n) = -g dt^2 n(n+1)/2
+    bool flat = true;                       // ftsp_midpoint(:,2) == 0 everywhere (the reference's plan, Controller.cpp:95)
+    std::vector<double> dU, SdU;            // nmid x NT each (only when !flat): Hinv q_p S' mid_z[idx:idx+N] and S_z times it
+    std::vector<double> SW;                 // npat x Fmax x NT (only when !flat): S_z W_p
+    std::vector<double> Wt;                 // npat x Fmax x NT (only when !flat): W_p re-strided to NT
 };
 
 // Returns ISMPC_OK or an ISMPC_E_* code; on error `err` explains.

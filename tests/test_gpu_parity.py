@@ -33,13 +33,22 @@ def O():
 
 
 _solvers = {}
+PATHS = ("affine", "dense")     # fast path (affine tables) and the per-tick MFMA formulation
 
 
-def solver_for(q, N, **over):
-    key = (N, tuple(sorted(over.items())))
+def solver_for(q, N, path="affine", plan=None, **over):
+    key = (N, path, plan, tuple(sorted(over.items())))
     if key not in _solvers:
         p = q.default_params(N=N, **over)
-        _solvers[key] = q.MPCSolver(q.reference_plan(params=p), params=p)
+        ftsp = q.reference_plan(params=p)
+        if plan == "stairs":
+            for i in range(1, ftsp.shape[0]):
+                ftsp[i, 2] = 0.01 * ((i // 3) % 4)
+        os.environ["ISMPC_PATH"] = path
+        try:
+            _solvers[key] = q.MPCSolver(ftsp, params=p)
+        finally:
+            os.environ.pop("ISMPC_PATH", None)
     return _solvers[key]
 
 
@@ -63,11 +72,12 @@ def load_golden(q, name):
     return z, z["tick_in"].view(q.TICK_IN).reshape(-1), z["tick_out"].view(q.TICK_OUT).reshape(-1)
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("N", HORIZONS)
-def test_golden_vectors(q, N):
+def test_golden_vectors(q, N, path):
     """Committed inputs + reference-qpOASES outputs (tests/golden/make_golden.py)."""
     z, tin, ref = load_golden(q, f"formB_vectors_N{N}.npz")
-    out = solver_for(q, N).solve_batch(tin)
+    out = solver_for(q, N, path).solve_batch(tin)
     assert (out["status"] == ref["status"]).all()          # incl. which instances are infeasible / in flight
     assert_parity(q, out, ref)
 
@@ -88,8 +98,9 @@ def test_config1_single_tick_through_reference_call_shape(q):
         assert err <= TOL and np.abs(nxt.comVel - ref["com_vel"][k]).max() <= TOL
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("N,scale", [(100, 1.0), (100, 2.0), (200, 1.0), (64, 1.0), (37, 1.0), (129, 0.5), (256, 0.5)])
-def test_against_oracle_seeded(q, O, N, scale):
+def test_against_oracle_seeded(q, O, N, scale, path):
     """Fresh seeded batch (SURVEY.md 8d generator around the N=100/200 nominal gait), oracle run here."""
     from quadruped_gait_generation_ismpc_amd import workload
     base = 200 if N > 150 else (100 if N > 50 else 50)
@@ -98,7 +109,7 @@ def test_against_oracle_seeded(q, O, N, scale):
         tin = tin[tin["simulation_time"] < 1250]
     orc = O.Oracle(O.default_params(N))
     ref, info = orc.solve(tin)
-    out = solver_for(q, N).solve_batch(tin)
+    out = solver_for(q, N, path).solve_batch(tin)
     ok = (ref["status"] & q.ST_ERROR_MASK) == 0
     # a QP within 1e-9 of the feasibility boundary may be classified either way: exclude from status equality
     assert ((out["status"] != ref["status"]) & ok).sum() == 0
@@ -106,12 +117,29 @@ def test_against_oracle_seeded(q, O, N, scale):
     assert_parity(q, out, ref)
 
 
-def test_decision_trajectories(q, O):
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("N", [50, 100, 150])
+def test_non_flat_plan(q, O, N, path):
+    """Footsteps at varying heights: mid_z enters f_z (MPCSolver.cpp:259) -- the dU / W tables of the fast
+    path, the suffix sums of the dense one."""
+    from quadruped_gait_generation_ismpc_amd import workload
+    tin = workload.make_batch(N, 64, seed=21)
+    s = solver_for(q, N, path, plan="stairs")
+    orc = O.Oracle(O.default_params(N), s.ftsp)
+    ref, info = orc.solve(tin)
+    flat, _ = O.Oracle(O.default_params(N)).solve(tin)
+    assert np.abs(ref["u0"][:, 0] - flat["u0"][:, 0]).max() > 1.0       # the heights do matter
+    out = s.solve_batch(tin)
+    assert_parity(q, out, ref)
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_decision_trajectories(q, O, path):
     """Full decisionVariables_z/_x/_y (MPCSolver.cpp:269,395,396) via the device-pointer entry point."""
     import torch
     N = 100
     z, tin, ref = load_golden(q, f"formB_vectors_N{N}.npz")
-    s = solver_for(q, N)
+    s = solver_for(q, N, path)
     d_in = q.to_device(tin)
     traj = torch.zeros((len(tin), 3, N), dtype=torch.float64, device="cuda:0")
     d_out = s.solve_batch_torch(d_in, u_traj=traj)
@@ -126,10 +154,11 @@ def test_decision_trajectories(q, O):
     assert np.array_equal(t[:, :, 0], out["u0"])
 
 
-@pytest.mark.parametrize("batch", [1, 15, 16, 17, 1000])
-def test_ragged_batches_and_batch_independence(q, batch):
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("batch", [1, 3, 15, 16, 17, 1000])
+def test_ragged_batches_and_batch_independence(q, batch, path):
     from quadruped_gait_generation_ismpc_amd import workload
-    s = solver_for(q, 100)
+    s = solver_for(q, 100, path)
     tin = workload.make_batch(100, 1024, seed=3)
     full = s.solve_batch(tin)
     part = s.solve_batch(tin[:batch])
@@ -180,13 +209,14 @@ def test_first_step_box_and_flight(q, O):
     assert np.all(out["u0"][fl][:, 1:] == 0.0) and np.all(out["u0"][fl][:, 0] == 0.0)
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("N,ticks", [(100, 600), (200, 300)])
-def test_closed_loop_rollout_on_device(q, N, ticks):
+def test_closed_loop_rollout_on_device(q, N, ticks, path):
     """ismpc_rollout_device = Controller.cpp:297-310,346-348,503-504 around solve(); against the
     committed nominal pre-roll (CPU oracle + reference qpOASES).  Counters bit exact."""
     import torch
     z, tin, ref = load_golden(q, f"preroll_N{N}.npz")
-    s = solver_for(q, N)
+    s = solver_for(q, N, path)
     st0 = tin[:1].copy()
     st0["simulation_time"] = 0.0; st0["footstep_counter"] = 0; st0["mpc_iter"] = 0; st0["control_iter"] = 0
     d_state = q.to_device(np.repeat(st0, 5))
