@@ -83,7 +83,11 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
+    from quadruped_gait_generation_ismpc_amd.distributed import shard_range, gather_records
     N, B = args.horizon, args.batch_per_gpu
+    first, count = shard_range(world * B, rank, world)
+    assert (first, count) == (rank * B, B)
+    counts = [B] * world
     p = q.default_params(N=N)
     solver = q.MPCSolver(q.reference_plan(params=p), params=p, device=local_rank)
     tick_in = workload.make_batch(N, B, first_instance=rank * B)         # this rank's shard, no communication
@@ -94,21 +98,31 @@ def main():
     def step():
         solver.solve_batch_torch(d_in, d_out)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_out)
+            gather_records(d_out, world, out=d_all, counts=counts)        # the one collective of the path
 
     for _ in range(args.warmup):
         step()
+    # Kernel duration for the roofline: HIP events on the launch stream (torch's current stream IS the stream
+    # the C ABI launches on).  An event pair around a ~10 us kernel reads several us high, so on one GPU the
+    # pair brackets the whole timed region (K back-to-back launches, nothing else on the stream) and the
+    # average launch interval is reported; with a collective in the loop each launch gets its own pair.
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()                   # torch's current stream == the stream the kernel is launched on
-        solver.solve_batch_torch(d_in, d_out)
-        ev[k][1].record()
-        if world > 1:
-            dist.all_gather_into_tensor(d_all, d_out)
+    if world == 1:
+        ev_region[0].record()
+        for k in range(args.steps):
+            solver.solve_batch_torch(d_in, d_out)
+        ev_region[1].record()
+    else:
+        for k in range(args.steps):
+            ev[k][0].record()
+            solver.solve_batch_torch(d_in, d_out)
+            ev[k][1].record()
+            gather_records(d_out, world, out=d_all, counts=counts)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -117,7 +131,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world == 1:
+        kernel_ms = ev_region[0].elapsed_time(ev_region[1]) / args.steps
+    else:
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     out = q.from_device(d_out, q.TICK_OUT)
     if world > 1:
@@ -146,7 +163,7 @@ def main():
             "qp_solves_per_s": 3.0 * value,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
-                         "kernel": "ismpc_tick_kernel<2>", "kernel_ms": kernel_ms,
+                         "kernel": ("ismpc_tick_dense<%d,16>" if os.environ.get("ISMPC_PATH") == "dense" else "ismpc_tick_affine<%d>") % ((N + 63) // 64), "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_launch": flops,
                          "note": "FP64 compute roofline (vector = matrix peak 78.6 TF); algorithmic flops 6N^2+20N per tick, "
                                  "shared vertical factor; algorithmic HBM bytes 152 B/tick are ~1e-4 of the HBM roofline"},

@@ -1,7 +1,8 @@
 """Builds the in-tree native libraries with hipcc for gfx950 (no JIT cache, no torch extension):
 
   libismpc_hip.so   kernels + C ABI of include/ismpc.h   (csrc/ismpc_hip.hip, csrc/ismpc_tables.cpp)
-  libmpcsolver.so   the C++ MPCSolver drop-in class over that ABI (csrc/mpcsolver_shim.cpp)
+
+The C++ MPCSolver drop-in (include/MPCSolver.hpp) is header-only over that ABI.
 """
 import os
 import shutil
@@ -11,7 +12,6 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 ROOT = os.path.dirname(PKG)
 LIB_HIP = os.path.join(PKG, "libismpc_hip.so")
-LIB_SHIM = os.path.join(PKG, "libmpcsolver.so")
 ARCH = "gfx950"
 
 
@@ -36,12 +36,6 @@ def build(force=False, verbose=False):
     if force or _stale(LIB_HIP, deps):
         subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
                                "-I", os.path.join(ROOT, "include")] + hip_src + ["-o", LIB_HIP], stdout=out)
-    shim_src = os.path.join(CSRC, "mpcsolver_shim.cpp")
-    if os.path.exists(shim_src):
-        sdeps = [shim_src, os.path.join(ROOT, "include", "MPCSolver.hpp"), os.path.join(ROOT, "include", "ismpc.h")]
-        if force or _stale(LIB_SHIM, sdeps):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
-                                   shim_src, "-o", LIB_SHIM, "-L", PKG, "-lismpc_hip", "-Wl,-rpath,$ORIGIN"], stdout=out)
     return LIB_HIP
 
 

@@ -1,0 +1,72 @@
+"""CPU-only, world_size 2 over gloo: the sharding of the batch axis and the single all-gather of output
+records that bench.py --gpus N uses (no GPU compute here: records are stand-ins derived from the inputs)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _fake_out(tin):
+    """Deterministic 80-byte stand-in for the kernel's output record of each input."""
+    from quadruped_gait_generation_ismpc_amd import TICK_OUT
+    o = np.zeros(len(tin), dtype=TICK_OUT)
+    o["com_pos"] = tin["com_pos"] + 0.01 * tin["com_vel"]
+    o["com_vel"] = tin["com_vel"]
+    o["u0"][:, 0] = tin["simulation_time"]
+    o["status"] = tin["mpc_iter"]; o["iters"] = tin["footstep_counter"]
+    return o
+
+
+def _worker(rank, world, port, global_batch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from quadruped_gait_generation_ismpc_amd import workload, TICK_OUT
+        from quadruped_gait_generation_ismpc_amd.distributed import shard_range, gather_records
+        first, count = shard_range(global_batch, rank, world)
+        tin = workload.make_batch(100, count, first_instance=first)           # no communication to build a shard
+        loc = _fake_out(tin)
+        loc_t = torch.from_numpy(loc.view(np.uint8).reshape(count, 80).copy())
+        allt = gather_records(loc_t, world)
+        got = allt.numpy().view(TICK_OUT).reshape(-1)
+        full = _fake_out(workload.make_batch(100, global_batch))
+        q.put((rank, first, count, got.tobytes() == full.tobytes(), len(got)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("global_batch", [64, 37])
+def test_shards_and_single_allgather(global_batch, built_libs):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, global_batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    assert [r[1] for r in res] == [0, res[0][2]] and sum(r[2] for r in res) == global_batch
+    assert all(r[3] for r in res) and all(r[4] == global_batch for r in res)
+
+
+def test_shard_ranges_partition_the_batch():
+    from quadruped_gait_generation_ismpc_amd.distributed import shard_range
+    for gb in (1, 7, 8, 65536, 65537):
+        for world in (1, 2, 4, 8):
+            pos = 0
+            for r in range(world):
+                f, c = shard_range(gb, r, world)
+                assert f == pos and c >= 0
+                pos += c
+            assert pos == gb
+    assert shard_range(65536, 3, 8) == (3 * 8192, 8192)
