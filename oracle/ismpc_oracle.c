@@ -488,6 +488,16 @@ int orc_qp_gi(int n, int nC, const double* H, const double* g0, const double* A,
     int* eqrow = (int*)malloc(sizeof(int)*(nC+1));
     int nI = 0, nE = 0, q = 0, neq_act = 0;
     memcpy(L, H, sizeof(double)*n*n);
+    int diagH = 1;
+    for (int i = 0; i < n && diagH; ++i)
+        for (int k = 0; k < n; ++k) if (i != k && H[i*n+k] != 0.0) { diagH = 0; break; }
+    if (diagH) {                      /* diagonal Hessian (Formulation A): factor, inverse and x0 are O(n) */
+        for (int i = 0; i < n; ++i) {
+            if (!(H[i*n+i] > 0.0)) { ret = 33; goto done; }
+            L[i*n+i] = sqrt(H[i*n+i]); J[i*n+i] = 1.0 / L[i*n+i]; x[i] = -g0[i] / H[i*n+i];
+        }
+        goto factored;
+    }
     /* Cholesky, lower */
     for (int j = 0; j < n; ++j) {
         double sum = L[j*n+j];
@@ -519,6 +529,7 @@ int orc_qp_gi(int n, int nC, const double* H, const double* g0, const double* A,
         for (int k = i + 1; k < n; ++k) s_ -= L[k*n+i]*x[k];
         x[i] = s_ / L[i*n+i];
     }
+factored:;
     double rnorm = 1.0;
     for (int c = 0; c < nC; ++c) {
         double lo = lbA[c], hi = ubA[c];

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Copies the reference's own known-answer DATA for Formulation A into small committed fixtures:
+the checked-in MATLAB trajectories AMR_code_DART/MATLAB_trajectories/**/Com{Trajectory,Velocity}_*.txt
+(3 columns, %e with 7 significant digits, one row per 10 ms tick).  Data only --
+no reference source text.  Also records the per-fixture generator parameters that reproduce them.
+
+Run:  python tests/golden/make_golden_a.py      (needs /root/reference)
+"""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/AMR_code_DART/MATLAB_trajectories"
+
+# name -> (directory, gait, phi, disp_A)            parameters per SURVEY.md A.3
+FIXTURES = {
+    "walk_phi0":      ("walking/phi0_10cm_50",   "walk", 0.0,        0.10),
+    "walk_phipi4":    ("walking/phipi4_10cm_50", "walk", np.pi / 4,  0.10),
+    "walk_phipi2":    ("walking/phipi2_10cm_50", "walk", np.pi / 2,  0.10),
+    "trot_phi0":      ("trotting/phi0",          "trot", 0.0,        0.15),
+    "trot_phipi4":    ("trotting/phipi4",        "trot", np.pi / 4,  0.10),
+    "trot_phipi4_15": ("trotting/phipi4/15cm",   "trot", np.pi / 4,  0.15),
+    "trot_phipi2":    ("trotting/phipi2",        "trot", np.pi / 2,  0.15),
+}
+
+
+def main():
+    meta = {}
+    for name, (d, gait, phi, dA) in FIXTURES.items():
+        files = os.listdir(os.path.join(REF, d))
+        traj = [f for f in files if f.startswith("ComTrajectory")][0]
+        vel = [f for f in files if f.startswith("ComVelocity")]
+        com = np.loadtxt(os.path.join(REF, d, traj))
+        arrs = {"com": com}
+        if vel:
+            arrs["vel"] = np.loadtxt(os.path.join(REF, d, vel[0]))
+        np.savez_compressed(os.path.join(HERE, f"formA_matlab_{name}.npz"), **arrs)
+        meta[name] = {"source": f"AMR_code_DART/MATLAB_trajectories/{d}/{traj}", "gait": gait, "phi": phi, "disp_A": dA,
+                      "rows": int(com.shape[0]), "has_velocity": bool(vel)}
+        print(name, com.shape, "vel" if vel else "-")
+    json.dump(meta, open(os.path.join(HERE, "formA_matlab_meta.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
