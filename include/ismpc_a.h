@@ -1,0 +1,110 @@
+/*
+ * ismpc_a.h -- C ABI of the MI355X-native "Formulation A" ISMPC tick (classic ISMPC with automatic
+ * footstep adaptation): the per-tick QP of the reference's MATLAB gait generators, which produced every
+ * checked-in trajectory fixture and whose stacked matrices the C++ MPCSolver constructor still allocates
+ * (AMR_code_DART/MPCSolver.cpp:34-71).  Reference interfaces replaced (paths relative to the reference root):
+ *
+ *   ismpc_a_plan            <->  trotting/init_quadruped.m:5-184 , walking/init_quadruped2.m:5-284
+ *                                (foot_plan, center = fs_plan)
+ *   ismpc_a_create          <->  walking/quad_walk_no_plots.m:6-110 / trotting/quad_as_bip_no_plots.m:6-103
+ *                                (constants, A_upd/B_upd, centreline cl_x/cl_y)
+ *   ismpc_a_tick_batch_device <-> one iteration of `for j = 1:sim_duration`:
+ *                                walking/quad_walk_no_plots.m:127-331,509-559 /
+ *                                trotting/quad_as_bip_no_plots.m:116-316,436-479
+ *                                (mapping, ZMP / kinematic / stability constraints, quadprog, LIP update,
+ *                                 footstep counter + plan shift + centreline rebuild)
+ *   ismpc_a_rollout_device  <->  the whole loop, closed on the device
+ *
+ * The swing-foot re-placement QPs (quad_walk_no_plots.m:336-504) edit foot_plan only and are not part of
+ * this ABI.  Conventions as ismpc.h: plain C, int status, no CPU fallback.
+ */
+#ifndef ISMPC_A_H
+#define ISMPC_A_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* per-instance status bits (ismpc_a_out.status) */
+#define ISMPC_A_ST_OK            0
+#define ISMPC_A_ST_X_INFEASIBLE  1    /* the x QP has no feasible point                         */
+#define ISMPC_A_ST_Y_INFEASIBLE  2
+#define ISMPC_A_ST_OVERFLOW      4    /* the horizon spans more than F-1 step boundaries: the .m file's
+                                         `mapping` outgrows its F+1 columns (needs F = ceil(C/step)+1) */
+#define ISMPC_A_ST_BAD_INDEX     8    /* j + P beyond the centreline, fc + F beyond the plan, or j outside
+                                         the current step [step (fc-1), step fc - 1]               */
+#define ISMPC_A_ST_ITER_LIMIT    16   /* active-set iteration limit hit (result is the last iterate)  */
+
+typedef struct ismpc_a_gait {           /* init_quadruped*.m:5-37 */
+    int32_t gait;                       /* 0 = trot (init_quadruped.m), 1 = walk (init_quadruped2.m) */
+    int32_t n_gait;                     /* N_gait = 100 */
+    double  disp_A, phi;                /* step length [m], heading [rad] */
+    double  disp_B, disp_C;             /* 0.259394, 0.88 */
+    double  disp_i, disp_o, disp_forw;  /* 0.4, 0.4, 0.5 */
+} ismpc_a_gait;
+
+typedef struct ismpc_a_params {         /* quad_walk_no_plots.m:15-45,270-271 */
+    int32_t C, P, F;                    /* control / preview horizon, footsteps: 100/200/3 (walk), 160/320/3 (trot) */
+    int32_t step, ds;                   /* step_duration, dsSamples: 50/30 (walk), 80/50 (trot) */
+    int32_t n_gait;                     /* NF */
+    double  dt;                         /* mpcTimeStep */
+    double  height;                     /* 0.56 */
+    double  grav;                       /* 9.8 (the scripts do not use 9.81) */
+    double  w;                          /* centroid_size = foot_size = 0.02 */
+    double  Qf;                         /* Qfootsteps: 1e9 (walk), 1e7 (trot) */
+    double  disp_forw, disp_forw_dummy, disp_L;   /* 0.5, 0.25, (disp_o + disp_i)/2 */
+} ismpc_a_params;
+
+/* everything the MATLAB loop carries from tick to tick, per instance (96 bytes) */
+typedef struct ismpc_a_state {
+    double  x, xd, xz, y, yd, yz;       /* CoM, CoM velocity, ZMP */
+    double  cur_x, cur_y;               /* current_xfs, current_yfs */
+    double  off_x, off_y;               /* fs_plan(:,c) = base plan + off (quad_walk_no_plots.m:535-536) */
+    int32_t fc;                         /* fsCounter, 1-based like the script */
+    int32_t j;                          /* tick about to run, 1-based */
+    int32_t rebuilt;                    /* 0: initial centreline (:86-99), 1: rebuilt one (:540-549) */
+    int32_t reserved;
+} ismpc_a_state;
+
+typedef struct ismpc_a_out {            /* 80 bytes */
+    double  com_before[2];              /* x_store(j), y_store(j): row j of ComTrajectory_*.txt */
+    double  vel_after[2];               /* xd_store(j), yd_store(j): row j of ComVelocity_*.txt */
+    double  u0[2];                      /* predicted_xzd(1), predicted_yzd(1) */
+    double  f0[2];                      /* predicted_xfs(1), predicted_yfs(1) */
+    int32_t status;
+    int32_t iters_x, iters_y;           /* active-set iterations */
+    int32_t active;                     /* final working-set sizes: x | y << 16 */
+} ismpc_a_out;
+
+typedef struct ismpc_a_handle ismpc_a_handle;
+
+void ismpc_a_params_default(int gait, ismpc_a_params* p);
+void ismpc_a_gait_default(int gait, double phi, double disp_A, ismpc_a_gait* g);
+
+/* Host: the plan generators.  foot_plan: (n_gait+1) x 8 row-major (BL, BR, FR, FL xy); center: n_gait x 2.
+ * Returns the number of foot_plan rows written (n_gait for trot, n_gait+1 for walk) or a negative error. */
+int ismpc_a_plan(const ismpc_a_gait* g, double* foot_plan, double* center);
+
+/* center = fs_plan (n_gait x 2 row-major).  disp_C sets the initial state (x = xz = disp_C/2). */
+int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, ismpc_a_handle** out);
+void ismpc_a_destroy(ismpc_a_handle* h);
+
+/* State the scripts start from (quad_walk_no_plots.m:52-62). */
+int ismpc_a_initial_state(const ismpc_a_handle* h, double disp_C, ismpc_a_state* st);
+
+/* One tick for every instance.  state is updated in place; push is NULL or batch x 2 impulsive velocity
+ * disturbances added before the QP (quad_walk_no_plots.m:134-148); out may be NULL. */
+int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const double* push_dev,
+                              ismpc_a_out* out_dev, void* stream);
+/* `ticks` ticks, out_traj NULL or ticks x batch records. */
+int ismpc_a_rollout_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, int ticks,
+                           ismpc_a_out* out_traj_dev, void* stream);
+
+const char* ismpc_a_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISMPC_A_H */

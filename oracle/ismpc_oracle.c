@@ -422,6 +422,10 @@ int orc_rollout(orc_solver* s, ismpc_tick_in* st, int first_frame, int ticks,
  * Same signature and return codes as the qpOASES shim (0 ok, 37 infeasible,
  * 64 iteration limit, 33 Hessian not positive definite).                  */
 #define GI_INF 1e20
+int orc_gi_last_active = 0;      /* diagnostics: size of the final working set of the last orc_qp_gi call */
+int orc_gi_max_active = 0;       /* ... and the largest working set seen since it was last reset */
+int orc_gi_dbg[4] = {0,0,0,0};   /* add failures, dual-only steps, drops, full steps */
+double orc_gi_orth_err = -1.0;   /* set when getenv("ORC_GI_DEBUG"): max |J'HJ - I| at exit */
 
 static void gi_delete(int n, int l, int* q, double* R, double* J, double* u, int* act)
 {
@@ -456,7 +460,9 @@ static int gi_add(int n, int* q, double* R, double* J, double* d, double* rnorm)
     for (int j = n - 1; j > qq; --j) {
         double a = d[j-1], b = d[j];
         double h = hypot(a, b);
-        if (h == 0.0) continue;
+        /* entries of d decay geometrically through chains of near-identity rotations and end up
+         * subnormal; a/h on subnormals is not a rotation any more (c^2+s^2 != 1) and destroys J'HJ = I */
+        if (h < 1e-280) { d[j] = 0.0; continue; }
         double c = a / h, s_ = b / h;
         d[j-1] = h; d[j] = 0.0;
         for (int k = 0; k < n; ++k) {
@@ -602,6 +608,7 @@ factored:;
             double t = (t1 < t2) ? t1 : t2;
             if (!isfinite(t)) { ret = 37; goto done; }
             if (!isfinite(t2)) {
+                orc_gi_dbg[1]++;
                 for (int k = 0; k < q; ++k) u[k] -= t * r[k];
                 u[q] += t;
                 cact[act[l]] = 0;
@@ -614,17 +621,28 @@ factored:;
             if (t == t2) {
                 if (!gi_add(n, &q, R, J, d, &rnorm)) {
                     /* numerically dependent: treat as satisfied */
+                    orc_gi_dbg[0]++;
                     act[q] = -1; u[q] = 0;
                     break;
                 }
                 cact[ip] = 1;
+                orc_gi_dbg[3]++;
                 break;
             }
+            orc_gi_dbg[2]++;
             cact[act[l]] = 0;
             { double uq = u[q]; int aq = act[q]; gi_delete(n, l, &q, R, J, u, act); u[q] = uq; act[q] = aq; u[q+1] = 0; act[q+1] = -1; }
         }
     }
 done:
+    if (getenv("ORC_GI_DEBUG") && ret != 33) {
+        double e = 0;
+        double* HJ = (double*)malloc(sizeof(double)*n*n);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s_ = 0; for (int k = 0; k < n; ++k) s_ += H[i*n+k]*J[k*n+j]; HJ[i*n+j] = s_; }
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s_ = 0; for (int k = 0; k < n; ++k) s_ += J[k*n+i]*HJ[k*n+j]; s_ -= (i == j); if (fabs(s_) > e) e = fabs(s_); }
+        free(HJ); orc_gi_orth_err = e;
+    }
+    orc_gi_last_active = q; if (q > orc_gi_max_active) orc_gi_max_active = q;
     if (nWSR) *nWSR = iter > 0 ? iter - 1 : 0;
     free(L); free(J); free(R); free(d); free(z); free(r); free(u); free(np); free(act);
     free(crow); free(csgn); free(crhs); free(cact); free(eqrow);

@@ -329,6 +329,49 @@ static int solve_axis(orc_a_sim* s, int axis, const double* mapping /* C x (F+1)
     return rv;
 }
 
+/* Structured view of the same per-axis QP (diagnostics / prototyping): stability row a, rhs b, ZMP band
+ * [zlo, zhi] per sample, mapping (C x (F+1)), kinematic bounds and the footstep reference. */
+int orc_a_axis_data(orc_a_sim* s, int axis, double* a, double* b, double* zlo, double* zhi, double* mapping_out,
+                    double* klo, double* khi, double* pref)
+{
+    const orc_a_params* p = &s->p;
+    const int C = p->C, P = p->P, F = p->F, j = s->st.j, fc = s->st.fc, ds = p->ds;
+    const double dt = p->dt, eta = s->eta;
+    const double pos = axis == 0 ? s->st.x : s->st.y, vel = axis == 0 ? s->st.xd : s->st.yd, zmp = axis == 0 ? s->st.xz : s->st.yz;
+    const double cur = axis == 0 ? s->st.cur_x : s->st.cur_y;
+    const double* fs = axis == 0 ? s->fsx : s->fsy;
+    const double* cl = axis == 0 ? s->clx : s->cly;
+    int pf = 0;
+    memset(mapping_out, 0, sizeof(double) * C * (F + 1));
+    for (int i = 1; i <= C; ++i) {
+        if (j + i >= fs_timing(s, fc + pf + 1)) pf = pf + 1;
+        const int rem = fs_timing(s, fc + pf + 1) - (j + i);
+        if (pf + 1 > F + 1 || (rem <= ds && pf + 2 > F + 1)) return -2;
+        if (rem > ds) mapping_out[(i-1)*(F+1) + pf] = 1;
+        else { mapping_out[(i-1)*(F+1) + pf] = (double)rem / ds; mapping_out[(i-1)*(F+1) + pf + 1] = 1 - (double)rem / ds; }
+    }
+    const double lambda = exp(-eta * dt);
+    double anticip = 0.0;
+    for (int i = C + 1; i <= P; ++i) anticip += exp(-eta * dt * i) * (1 - exp(-eta * dt)) * (cl[j + i] - cur);
+    anticip += exp(-eta * dt * P) * (cl[P] - cur);
+    for (int i = 0; i < C; ++i)
+        a[i] = (1 / eta) * (1 - lambda) / (1 - pow(lambda, C)) * exp(-eta * dt * i) - dt * 1.0 * exp(-eta * dt * C);
+    *b = pos + vel / eta - zmp - anticip;
+    for (int i = 1; i <= C; ++i) {
+        const double m1 = mapping_out[(i-1)*(F+1)];
+        zhi[i-1] = 1.0 * (-zmp + p->w / 2) + m1 * cur;
+        zlo[i-1] = -(-1.0 * (-zmp - p->w / 2) - m1 * cur);
+    }
+    for (int r = 1; r <= F; ++r) {
+        double bup = axis == 0 ? p->disp_forw : (p->disp_L / 2 + p->disp_L / 2), blo;
+        if (fc == 1 && r == 1) bup = axis == 0 ? p->disp_forw_dummy : (p->disp_L / 2 + p->disp_L / 2);
+        blo = bup;
+        if (r == 1) { bup = bup + cur; blo = blo - cur; }
+        khi[r-1] = bup; klo[r-1] = -blo; pref[r-1] = fs[fc + r];
+    }
+    return 0;
+}
+
 /* One iteration of `for j = 1:sim_duration` (push = impulsive velocity disturbance added first, :134-148). */
 int orc_a_tick(orc_a_sim* s, double push_x, double push_y, orc_a_tick_out* out, double* sol_x, double* sol_y)
 {

@@ -66,6 +66,7 @@ def _lib():
         lib.orc_a_set_plan.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int]
         lib.orc_a_tick.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.orc_a_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.orc_a_axis_data.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
         lib._a_ready = True
     return lib
 
@@ -107,6 +108,16 @@ class SimA:
         _lib().orc_a_tick(self._h, float(push[0]), float(push[1]), out.ctypes.data_as(C.c_void_p),
                           sx.ctypes.data_as(C.c_void_p), sy.ctypes.data_as(C.c_void_p))
         return (out[0], sx, sy) if want_solution else out[0]
+
+    def axis_data(self, axis):
+        """Structured per-axis QP of the NEXT tick: dict(a, b, zlo, zhi, M [C, F+1], klo, khi, pref)."""
+        Cn, F = self.p.C, self.p.F
+        a = np.zeros(Cn); b = np.zeros(1); zlo = np.zeros(Cn); zhi = np.zeros(Cn); M = np.zeros((Cn, F + 1))
+        klo = np.zeros(F); khi = np.zeros(F); pref = np.zeros(F)
+        rc = _lib().orc_a_axis_data(self._h, axis, *[x.ctypes.data_as(C.c_void_p) for x in (a, b, zlo, zhi, M, klo, khi, pref)])
+        if rc != 0:
+            raise RuntimeError("mapping overflow")
+        return dict(a=a, b=float(b[0]), zlo=zlo, zhi=zhi, M=M, klo=klo, khi=khi, pref=pref)
 
     @property
     def state(self):

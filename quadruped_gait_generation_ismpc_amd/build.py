@@ -1,6 +1,6 @@
 """Builds the in-tree native libraries with hipcc for gfx950 (no JIT cache, no torch extension):
 
-  libismpc_hip.so   kernels + C ABI of include/ismpc.h   (csrc/ismpc_hip.hip, csrc/ismpc_tables.cpp)
+  libismpc_hip.so   kernels + C ABI of include/ismpc.h   (csrc/ismpc_hip.hip, csrc/ismpc_a_hip.hip, csrc/ismpc_tables.cpp)
 
 The C++ MPCSolver drop-in (include/MPCSolver.hpp) is header-only over that ABI.
 """
@@ -30,8 +30,9 @@ def _stale(target, sources):
 
 
 def build(force=False, verbose=False):
-    hip_src = [os.path.join(CSRC, "ismpc_hip.hip"), os.path.join(CSRC, "ismpc_tables.cpp")]
-    deps = hip_src + [os.path.join(CSRC, "ismpc_tables.hpp"), os.path.join(ROOT, "include", "ismpc.h")]
+    hip_src = [os.path.join(CSRC, "ismpc_hip.hip"), os.path.join(CSRC, "ismpc_a_hip.hip"), os.path.join(CSRC, "ismpc_tables.cpp")]
+    deps = hip_src + [os.path.join(CSRC, "ismpc_tables.hpp"), os.path.join(ROOT, "include", "ismpc.h"),
+                      os.path.join(ROOT, "include", "ismpc_a.h")]
     out = None if verbose else subprocess.DEVNULL
     if force or _stale(LIB_HIP, deps):
         subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -1,0 +1,770 @@
+// Formulation A (classic ISMPC with footstep adaptation) on gfx950: kernels + the C ABI of include/ismpc_a.h.
+//
+// One 256-thread workgroup solves ONE per-axis QP of one instance (walking/quad_walk_no_plots.m:153-293):
+//
+//   min 1/2 |u|^2 + Qf/2 |f - p|^2      u = ZMP velocities (C), f = footsteps (F)
+//   s.t. a'u = b                          stability (anticipative tail)          (:227-242)
+//        lo_i <= dt cumsum(u)_i - M_i f <= hi_i     ZMP band around the mapped footstep  (:153-181)
+//        -bl_r <= f_r - f_{r-1} <= bu_r             kinematic                           (:187-222)
+//
+// The reference hands the stacked dense matrices to quadprog (MATLAB) / qpOASES / HPIPM.  Here the Hessian
+// is diagonal and every row has a closed form, so a DUAL ACTIVE-SET method in RANGE-SPACE form never builds
+// a matrix over the variables: with N the active normals it keeps S^-1 = (N' H^-1 N)^-1 (size = working
+// set), whose entries come from closed-form inner products (dt^2 min(i,k) + M_i.M_k / Qf, ...).  A step is
+//   d = N' H^-1 n+ (O(1) per active row),  r = S^-1 d (mat-vec),  z = H^-1 (n+ - N r) (impulses + one
+//   suffix scan),  step lengths exactly as Goldfarb-Idnani,  then a rank-1 border (add) or Schur (drop)
+//   update of S^-1 -- all data parallel, no triangular solve, no Givens chain.
+// After convergence two refinement passes on the final working set remove the drift of the explicit
+// inverse and the feasibility of every row is re-checked (the loop resumes if anything moved).
+// Results are the unique minimiser: validated against the oracle's null-space Goldfarb-Idnani and the
+// reference's qpOASES (tests/).  No CPU fallback.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include <new>
+#include <algorithm>
+#include "../../include/ismpc_a.h"
+
+namespace {
+
+constexpr int T = 256;                 // threads per workgroup; requires C + F <= 256
+constexpr int MAXF = 8;
+constexpr int QCAP = 264;              // capacity of the working set (>= C + F + 1)
+
+struct DevA {
+    int C, P, F, step, ds, n_gait, ncl, ldq, max_iter;
+    double dt, eta, w, Qf, disp_forw, disp_forw_dummy, disp_L, aa, wP, sumw;
+    double Au[9], Bu[3];
+    const double *a, *PA, *wtail;      // stability row, its prefix sums PA[i] = sum_{k<i} a_k, tail weights (index i-(C+1))
+    const double *fsx, *fsy;           // base plan, 0-based (fs_plan(k+1))
+    const double *clx0, *cly0, *clx1, *cly1;   // centreline: initial / rebuilt structure, 0-based (cl(k+1))
+    double* scratch;                   // per-workgroup S^-1 : ldq x ldq doubles each
+};
+
+// ---- wave / block primitives ------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, bool BOUND_ZERO>
+__device__ __forceinline__ double dpp64(double old, double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, 0xf, BOUND_ZERO);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, 0xf, BOUND_ZERO);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_scan_up(double v)   // inclusive prefix sum over the 64 lanes
+{
+    v += dpp64<0x111, 0xf, true>(0.0, v);
+    v += dpp64<0x112, 0xf, true>(0.0, v);
+    v += dpp64<0x114, 0xf, true>(0.0, v);
+    v += dpp64<0x118, 0xf, true>(0.0, v);
+    v += dpp64<0x142, 0xa, false>(0.0, v);
+    v += dpp64<0x143, 0xc, false>(0.0, v);
+    return v;
+}
+
+struct Shared {
+    double u[T], zu[T], imp[T], zlo[T], zhi[T], w1[T], w2[T], a[T], PA[T + 1];
+    int k1[T];
+    double f[MAXF + 1], zf[MAXF + 1], pref[MAXF + 1], klo[MAXF + 1], khi[MAXF + 1];
+    int act_row[QCAP]; double act_sgn[QCAP], mu[QCAP], r[QCAP], dp[QCAP];
+    int state[T + MAXF + 1];            // per row (1..C+F): 0 free, +1 lower active, -1 upper active
+    double red[T]; int redi[T];
+    double wsum[8];
+    double zfpart[4][MAXF + 1];
+    // scalars
+    double b, sviol, sg, gamma, npn, t, t1, t2, mu_p, rowval;
+    int q, row, drop, flag, iters, status;
+};
+
+// inclusive prefix sum over the workgroup (thread order); every thread calls
+__device__ __forceinline__ double block_scan_incl(Shared& s, double v, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const double p = wave_scan_up(v);
+    if (lane == 63) s.wsum[wave] = p;
+    __syncthreads();
+    double add = 0.0;
+    for (int wv = 0; wv < wave; ++wv) add += s.wsum[wv];
+    __syncthreads();
+    return p + add;
+}
+// sum over the workgroup, same value (bitwise) in every thread
+__device__ __forceinline__ double block_sum(Shared& s, double v, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const double p = wave_scan_up(v);
+    if (lane == 63) s.wsum[wave] = p;
+    __syncthreads();
+    const double tot = ((s.wsum[0] + s.wsum[1]) + s.wsum[2]) + s.wsum[3];
+    __syncthreads();
+    return tot;
+}
+// minimum of v with its index (ties: smallest index), broadcast to all threads; v = +inf means "no candidate"
+__device__ __forceinline__ void block_argmin(Shared& s, double v, int idx, int tid, double& vmin, int& imin)
+{
+    s.red[tid] = v; s.redi[tid] = idx;
+    __syncthreads();
+    if (tid < 16) {
+        double bv = s.red[tid * 16]; int bi = s.redi[tid * 16];
+        for (int k = 1; k < 16; ++k) {
+            const double cv = s.red[tid * 16 + k]; const int ci = s.redi[tid * 16 + k];
+            if (cv < bv || (cv == bv && ci < bi)) { bv = cv; bi = ci; }
+        }
+        s.red[tid * 16] = bv; s.redi[tid * 16] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = s.red[0]; int bi = s.redi[0];
+        for (int k = 1; k < 16; ++k) {
+            const double cv = s.red[k * 16]; const int ci = s.redi[k * 16];
+            if (cv < bv || (cv == bv && ci < bi)) { bv = cv; bi = ci; }
+        }
+        s.red[0] = bv; s.redi[0] = bi;
+    }
+    __syncthreads();
+    vmin = s.red[0]; imin = s.redi[0];
+    __syncthreads();
+}
+
+// ---- closed-form H^-1 inner products of constraint rows (row 0 = stability, 1..C = ZMP, C+1..C+F = kinematic)
+__device__ __forceinline__ double mdot(const Shared& s, int i, int k)   // M_i . M_k over the footstep columns 1..F
+{
+    const int a1 = s.k1[i - 1], b1 = s.k1[k - 1];
+    const double aw1 = s.w1[i - 1], aw2 = s.w2[i - 1], bw1 = s.w1[k - 1], bw2 = s.w2[k - 1];
+    double acc = 0.0;
+    // entries: (a1 -> aw1), (a1+1 -> aw2) ; column 0 is the current footstep (not a variable)
+    if (a1 >= 1) { if (a1 == b1) acc += aw1 * bw1; else if (a1 == b1 + 1) acc += aw1 * bw2; }
+    { const int c = a1 + 1; if (c == b1 && b1 >= 1) acc += aw2 * bw1; else if (c == b1 + 1) acc += aw2 * bw2; }
+    return acc;
+}
+__device__ __forceinline__ double mcol(const Shared& s, int i, int r)   // M_i[r], r in 1..F (0 outside)
+{
+    if (r < 1) return 0.0;
+    const int a1 = s.k1[i - 1];
+    if (r == a1) return s.w1[i - 1];
+    if (r == a1 + 1) return s.w2[i - 1];
+    return 0.0;
+}
+__device__ __forceinline__ double ip_rows(const Shared& s, const DevA& c, int r1, int r2)
+{
+    if (r1 > r2) { const int t_ = r1; r1 = r2; r2 = t_; }
+    const int C = c.C;
+    if (r1 == 0) {
+        if (r2 == 0) return c.aa;
+        if (r2 <= C) return c.dt * s.PA[r2];
+        return 0.0;
+    }
+    if (r2 <= C) return c.dt * c.dt * (double)r1 + mdot(s, r1, r2) / c.Qf;       // min(r1, r2) = r1
+    if (r1 <= C) { const int r = r2 - C; return (-mcol(s, r1, r) + mcol(s, r1, r - 1)) / c.Qf; }
+    const int ra = r1 - C, rb = r2 - C;
+    if (ra == rb) return (1.0 + (ra >= 2 ? 1.0 : 0.0)) / c.Qf;
+    return (rb - ra == 1) ? -1.0 / c.Qf : 0.0;
+}
+
+// x += H^-1 N coef : adds  sum_j coef_j * (row_j)  scaled by H^-1 to (u, f).  coef[j] for j < q in s.dp (signed,
+// already multiplied by the row's sign); optional extra row `xrow` with coefficient xc.  Result in s.zu / s.zf.
+__device__ __forceinline__ void build_direction(Shared& s, const DevA& c, int tid, int q, int xrow, double xc)
+{
+    const int C = c.C, F = c.F;
+    if (tid < C) s.imp[tid] = 0.0;
+    __syncthreads();
+    // ZMP rows: dt on u[0..i-1]  ->  impulse at i-1, suffix-summed below (a row is active at most once)
+    double fpart[MAXF + 1];
+#pragma unroll
+    for (int k = 0; k <= MAXF; ++k) fpart[k] = 0.0;
+    double ce = 0.0;
+    for (int j = tid; j <= q; j += T) {
+        int row; double cf;
+        if (j < q) { row = s.act_row[j]; cf = s.dp[j]; } else { row = xrow; cf = xc; }
+        if (row < 0 || cf == 0.0) continue;
+        if (row == 0) ce += cf;
+        else if (row <= C) {
+            s.imp[row - 1] += cf * c.dt;
+            const int a1 = s.k1[row - 1];
+            if (a1 >= 1) fpart[a1] -= cf * s.w1[row - 1];
+            if (a1 + 1 <= F) fpart[a1 + 1] -= cf * s.w2[row - 1];
+        } else {
+            const int r = row - C;
+            fpart[r] += cf;
+            if (r >= 2) fpart[r - 1] -= cf;
+        }
+    }
+    // note: two different active ZMP rows never share an index, and the extra row is not active: no write race
+    const double cetot = block_sum(s, ce, tid);
+    // footstep parts: fixed-order reduction (bit reproducible)
+    for (int k = 1; k <= F; ++k) {
+        const double tot = block_sum(s, fpart[k], tid);
+        if (tid == 0) s.zf[k] = tot / c.Qf;
+    }
+    // suffix sum of the impulses = total - exclusive prefix
+    const double v = (tid < C) ? s.imp[tid] : 0.0;
+    const double incl = block_scan_incl(s, v, tid);
+    const double tot = block_sum(s, v, tid);
+    if (tid < C) s.zu[tid] = (tot - (incl - v)) + cetot * s.a[tid];
+    __syncthreads();
+}
+
+// value of constraint rows for the current x: thread tid < C gets zeta_{tid+1}, threads C..C+F-1 get kin_{tid-C+1}
+__device__ __forceinline__ double row_value(Shared& s, const DevA& c, int tid)
+{
+    const int C = c.C, F = c.F;
+    const double cum = block_scan_incl(s, (tid < C) ? s.u[tid] : 0.0, tid);
+    if (tid < C) {
+        const int a1 = s.k1[tid];
+        double mf = 0.0;
+        if (a1 >= 1) mf += s.w1[tid] * s.f[a1];
+        if (a1 + 1 <= F) mf += s.w2[tid] * s.f[a1 + 1];
+        return c.dt * cum - mf;
+    }
+    if (tid < C + F) { const int r = tid - C + 1; return s.f[r] - (r >= 2 ? s.f[r - 1] : 0.0); }
+    return 0.0;
+}
+
+__global__ __launch_bounds__(T)
+void ismpc_a_tick_kernel(const DevA c, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
+                         const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch)
+{
+    __shared__ Shared s;
+    const int tid = threadIdx.x;
+    const int C = c.C, F = c.F, P = c.P;
+    double* Sinv = c.scratch + (size_t)blockIdx.x * c.ldq * c.ldq;
+    const int ldq = c.ldq;
+
+    for (int work = blockIdx.x; work < 2 * batch; work += gridDim.x) {
+        const int inst = work >> 1, axis = work & 1;
+        // the two axes of an instance are separate work items: both read the PREVIOUS state (state_in, a copy
+        // made by the host entry point) and each writes only its own fields of `state`
+        const ismpc_a_state st = state_in[inst];
+        const double pos = axis == 0 ? st.x : st.y;
+        const double vel = (axis == 0 ? st.xd : st.yd) + (push ? push[inst * 2 + axis] : 0.0);
+        const double zmp = axis == 0 ? st.xz : st.yz;
+        const double cur = axis == 0 ? st.cur_x : st.cur_y;
+        const double off = axis == 0 ? st.off_x : st.off_y;
+        const int j = st.j, fc = st.fc;
+        const double* fs = axis == 0 ? c.fsx : c.fsy;
+        const double* cl = st.rebuilt ? (axis == 0 ? c.clx1 : c.cly1) : (axis == 0 ? c.clx0 : c.cly0);
+        const double cloff = st.rebuilt ? off : 0.0;
+        int status = 0;
+        // ---- validity of indices: fs_plan(fc+1 .. fc+F), cl(j+C+1 .. j+P), j inside step fc
+        if (fc < 1 || fc + F > c.n_gait || j < 1 || j + P > c.ncl || j < c.step * (fc - 1) || j > c.step * fc - 1)
+            status |= ISMPC_A_ST_BAD_INDEX;
+
+        // ---- mapping (quad_walk_no_plots.m:153-171), bounds (:173-181), stability data
+        if (tid < C) {
+            const int i = tid + 1;
+            int pf = (j + i) / c.step - fc + 1; if (pf < 0) pf = 0;
+            const int rem = c.step * (fc + pf) - (j + i);
+            double w1, w2;
+            if (rem > c.ds) { w1 = 1.0; w2 = 0.0; } else { w1 = (double)rem / c.ds; w2 = 1.0 - (double)rem / c.ds; }
+            s.k1[tid] = pf; s.w1[tid] = w1; s.w2[tid] = w2;
+            const double m1 = (pf == 0) ? w1 : 0.0;
+            s.zhi[tid] = 1.0 * (-zmp + c.w / 2) + m1 * cur;
+            s.zlo[tid] = -(-1.0 * (-zmp - c.w / 2) - m1 * cur);
+            s.a[tid] = c.a[tid]; s.u[tid] = 0.0;
+            s.red[tid] = (pf > F || (w2 != 0.0 && pf + 1 > F) || (rem <= c.ds && pf + 1 > F)) ? 1.0 : 0.0;
+        } else s.red[tid] = 0.0;
+        for (int k = tid; k <= C; k += T) s.PA[k] = c.PA[k];
+        for (int k = tid; k < C + F + 1; k += T) s.state[k] = 0;
+        __syncthreads();
+        const double ovf = block_sum(s, s.red[tid], tid);
+        if (ovf > 0.0) status |= ISMPC_A_ST_OVERFLOW;
+        // anticipative tail (:227-231), xfs_store(fsCounter) == current footstep
+        double tl = 0.0;
+        if (!(status & ISMPC_A_ST_BAD_INDEX))
+            for (int i = C + 1 + tid; i <= P; i += T) tl += c.wtail[i - (C + 1)] * ((cl[j + i - 1] + cloff) - cur);
+        double tail = block_sum(s, tl, tid);
+        if (!(status & ISMPC_A_ST_BAD_INDEX)) tail += c.wP * ((cl[P - 1] + cloff) - cur);
+        if (tid == 0) {
+            s.b = pos + vel / c.eta - zmp - tail;
+            for (int r = 1; r <= F; ++r) {
+                double bup = axis == 0 ? c.disp_forw : (c.disp_L / 2 + c.disp_L / 2);
+                if (fc == 1 && r == 1) bup = axis == 0 ? c.disp_forw_dummy : (c.disp_L / 2 + c.disp_L / 2);
+                double blo = bup;
+                if (r == 1) { bup = bup + cur; blo = blo - cur; }
+                s.khi[r] = bup; s.klo[r] = -blo;
+                const double pr = (status & ISMPC_A_ST_BAD_INDEX) ? 0.0 : fs[fc + r - 1] + off;
+                s.pref[r] = pr; s.f[r] = pr;                       // unconstrained minimiser: u = 0, f = p
+            }
+            s.q = 0; s.iters = 0; s.status = status;
+        }
+        __syncthreads();
+
+        int q = 0, iters = 0;
+        if (status == 0) {
+            // ---- equality first: n = (a, 0); from x = (0, p): t = b / a'a
+            {
+                const double t0 = s.b / c.aa;
+                if (tid < C) s.u[tid] = t0 * s.a[tid];
+                if (tid == 0) { s.act_row[0] = 0; s.act_sgn[0] = 1.0; s.mu[0] = t0; Sinv[0] = 1.0 / c.aa; }
+                q = 1;
+                __syncthreads();
+            }
+            bool resumed = false;
+            for (;;) {
+                // ======== outer: most violated inactive row (normalised by its H^-1 norm) ========
+                const double v = row_value(s, c, tid);
+                double cand = INFINITY; int cidx = 0;
+                if (tid < C + F) {
+                    const int row = tid + 1;
+                    if (s.state[row] == 0) {
+                        const double lo = tid < C ? s.zlo[tid] : s.klo[tid - C + 1];
+                        const double hi = tid < C ? s.zhi[tid] : s.khi[tid - C + 1];
+                        const double vl = v - lo, vh = hi - v;
+                        const double tol = 1e-11 * (fabs(v) + fmax(fabs(lo), fabs(hi))) + 1e-13;
+                        const double nrm = sqrt(ip_rows(s, c, row, row));
+                        if (vl < -tol) { cand = vl / nrm; cidx = 2 * row; }
+                        if (vh < -tol && vh / nrm < cand) { cand = vh / nrm; cidx = 2 * row + 1; }
+                    }
+                }
+                double vmin; int imin;
+                block_argmin(s, cand, cidx, tid, vmin, imin);
+                if (!(vmin < 0.0)) {
+                    // ---- converged on this working set: two refinement passes (N'x = bounds exactly), then re-check
+                    if (resumed) break;
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const double vv = row_value(s, c, tid);
+                        if (tid < C + F && s.state[tid + 1] != 0) s.red[tid] = vv;
+                        __syncthreads();
+                        // residual per active row (signed), then dm = S^-1 res
+                        if (tid < q) {
+                            const int row = s.act_row[tid];
+                            double res;
+                            if (row == 0) {
+                                res = 0.0;      // filled below by the block (needs a'u)
+                            } else {
+                                const double sgn = s.act_sgn[tid];
+                                const double bound = row <= C ? (sgn > 0 ? s.zlo[row - 1] : s.zhi[row - 1])
+                                                              : (sgn > 0 ? s.klo[row - C] : s.khi[row - C]);
+                                res = sgn * (bound - s.red[row - 1]);
+                            }
+                            s.r[tid] = res;
+                        }
+                        const double au = block_sum(s, (tid < C) ? s.a[tid] * s.u[tid] : 0.0, tid);
+                        if (tid == 0) s.r[0] = s.b - au;
+                        __syncthreads();
+                        if (tid < q) {
+                            double acc = 0.0;
+                            for (int k = 0; k < q; ++k) acc += Sinv[(size_t)k * ldq + tid] * s.r[k];
+                            s.dp[tid] = acc * s.act_sgn[tid];
+                        }
+                        __syncthreads();
+                        build_direction(s, c, tid, q, -1, 0.0);
+                        if (tid < C) s.u[tid] += s.zu[tid];
+                        if (tid >= 1 && tid <= F) s.f[tid] += s.zf[tid];
+                        __syncthreads();
+                    }
+                    resumed = true;
+                    continue;                                   // one more feasibility sweep
+                }
+                resumed = false;
+                const int row = imin >> 1;
+                const double sg = (imin & 1) ? -1.0 : 1.0;
+                double sviol;
+                {
+                    const int rt = row - 1;                      // thread that holds this row's value
+                    if (tid == rt) {
+                        const double lo = rt < C ? s.zlo[rt] : s.klo[rt - C + 1];
+                        const double hi = rt < C ? s.zhi[rt] : s.khi[rt - C + 1];
+                        s.sviol = sg > 0 ? v - lo : hi - v;
+                    }
+                    __syncthreads();
+                    sviol = s.sviol;
+                }
+                double mu_p = 0.0;
+                const double npn = ip_rows(s, c, row, row);
+                // ======== inner: steps until the row is added (Goldfarb-Idnani step logic) ========
+                for (;;) {
+                    if (++iters > c.max_iter) { status |= ISMPC_A_ST_ITER_LIMIT; break; }
+                    // d = N' H^-1 n+
+                    if (tid < q) s.dp[tid] = sg * s.act_sgn[tid] * ip_rows(s, c, row, s.act_row[tid]);
+                    __syncthreads();
+                    // r = S^-1 d
+                    double racc = 0.0;
+                    if (tid < q) {
+                        for (int k = 0; k < q; ++k) racc += Sinv[(size_t)k * ldq + tid] * s.dp[k];
+                        s.r[tid] = racc;
+                    }
+                    const double dr = block_sum(s, (tid < q) ? s.dp[tid] * racc : 0.0, tid);
+                    const double gamma = npn - dr;
+                    // dual step length: min over active inequalities with r > 0 of mu / r
+                    double tc = INFINITY;
+                    if (tid >= 1 && tid < q && racc > 0.0) tc = s.mu[tid] / racc;
+                    double t1; int l;
+                    block_argmin(s, tc, tid, tid, t1, l);
+                    const double t2 = (gamma > 1e-12 * npn) ? -sviol / gamma : INFINITY;
+                    const double t = fmin(t1, t2);
+                    if (!(t < INFINITY)) { status |= (axis == 0 ? ISMPC_A_ST_X_INFEASIBLE : ISMPC_A_ST_Y_INFEASIBLE); break; }
+                    if (t2 < INFINITY) {
+                        // z = H^-1 (n+ - N r): coefficients -r_j sign_j on the active rows, +sg on the new one
+                        if (tid < q) s.dp[tid] = -racc * s.act_sgn[tid];
+                        __syncthreads();
+                        build_direction(s, c, tid, q, row, sg);
+                        if (tid < C) s.u[tid] += t * s.zu[tid];
+                        if (tid >= 1 && tid <= F) s.f[tid] += t * s.zf[tid];
+                    }
+                    if (tid < q) s.mu[tid] -= t * racc;
+                    mu_p += t;
+                    __syncthreads();
+                    if (t2 < INFINITY && t == t2) {
+                        // ---- full step: border update of S^-1, append the row
+                        const double ig = 1.0 / gamma;
+                        if (tid < q) {
+                            const double rj = s.r[tid];
+                            for (int k = 0; k < q; ++k) Sinv[(size_t)k * ldq + tid] += s.r[k] * rj * ig;
+                            Sinv[(size_t)q * ldq + tid] = -rj * ig;
+                            Sinv[(size_t)tid * ldq + q] = -rj * ig;
+                        }
+                        if (tid == 0) {
+                            Sinv[(size_t)q * ldq + q] = ig;
+                            s.act_row[q] = row; s.act_sgn[q] = sg; s.mu[q] = mu_p; s.state[row] = sg > 0 ? 1 : -1;
+                        }
+                        ++q;
+                        __syncthreads();
+                        break;
+                    }
+                    // ---- partial step: drop working-set entry l (Schur update), keep going with the same row
+                    {
+                        const double piv = Sinv[(size_t)l * ldq + l];
+                        __syncthreads();
+                        if (tid < q) s.r[tid] = Sinv[(size_t)l * ldq + tid];      // column l (symmetric)
+                        __syncthreads();
+                        if (tid < q && tid != l) {
+                            const double cj = s.r[tid] / piv;
+                            for (int k = 0; k < q; ++k) if (k != l) Sinv[(size_t)k * ldq + tid] -= s.r[k] * cj;
+                        }
+                        __syncthreads();
+                        // move the last entry into slot l
+                        const int last = q - 1;
+                        if (l != last) {
+                            if (tid < q && tid != l) {
+                                const double vlast = Sinv[(size_t)last * ldq + tid];
+                                Sinv[(size_t)l * ldq + tid] = vlast;
+                                Sinv[(size_t)tid * ldq + l] = vlast;
+                            }
+                            __syncthreads();
+                            if (tid == 0) Sinv[(size_t)l * ldq + l] = Sinv[(size_t)last * ldq + last];
+                        }
+                        if (tid == 0) {
+                            s.state[s.act_row[l]] = 0;
+                            if (l != last) { s.act_row[l] = s.act_row[last]; s.act_sgn[l] = s.act_sgn[last]; s.mu[l] = s.mu[last]; }
+                        }
+                        --q;
+                        __syncthreads();
+                    }
+                    // violation of the row at the new point
+                    {
+                        const double vv = row_value(s, c, tid);
+                        const int rt = row - 1;
+                        if (tid == rt) {
+                            const double lo = rt < C ? s.zlo[rt] : s.klo[rt - C + 1];
+                            const double hi = rt < C ? s.zhi[rt] : s.khi[rt - C + 1];
+                            s.sviol = sg > 0 ? vv - lo : hi - vv;
+                        }
+                        __syncthreads();
+                        sviol = s.sviol;
+                    }
+                }
+                if (status != 0) break;
+            }
+        }
+
+        // ---- LIP update (:297-322), footstep bookkeeping (:522-556), outputs
+        __syncthreads();
+        if (tid == 0) {
+            const double u0 = (status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) ? 0.0 : s.u[0];
+            const double f0 = (status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) ? cur : s.f[1];
+            const double p0 = pos, v0 = vel, z0 = zmp;
+            const double np_ = (c.Au[0] * p0 + c.Au[1] * v0 + c.Au[2] * z0) + c.Bu[0] * u0;
+            const double nv_ = (c.Au[3] * p0 + c.Au[4] * v0 + c.Au[5] * z0) + c.Bu[1] * u0;
+            const double nz_ = (c.Au[6] * p0 + c.Au[7] * v0 + c.Au[8] * z0) + c.Bu[2] * u0;
+            ismpc_a_state* so = state + inst;
+            const bool ok = (status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) == 0;
+            const bool stepped = ok && (j + 1 >= c.step * fc);
+            if (ok) {
+                if (axis == 0) { so->x = np_; so->xd = nv_; so->xz = nz_; } else { so->y = np_; so->yd = nv_; so->yz = nz_; }
+                if (stepped) {
+                    const double noff = f0 - fs[fc];                  // predicted - fs_plan(fc+1)  (base plan)
+                    if (axis == 0) { so->cur_x = f0; so->off_x = noff; } else { so->cur_y = f0; so->off_y = noff; }
+                }
+                if (axis == 0) { so->j = j + 1; if (stepped) { so->fc = fc + 1; so->rebuilt = 1; } }
+            }
+            if (out) {
+                ismpc_a_out* o = out + inst;
+                o->com_before[axis] = pos; o->vel_after[axis] = ok ? nv_ : vel; o->u0[axis] = u0; o->f0[axis] = f0;
+                if (axis == 0) { o->iters_x = iters; atomicOr(&o->status, status); atomicOr(&o->active, q & 0xffff); }
+                else { o->iters_y = iters; atomicOr(&o->status, status); atomicOr(&o->active, (q & 0xffff) << 16); }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void ismpc_a_clear_out(ismpc_a_out* out, int batch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < batch) { out[i].status = 0; out[i].active = 0; out[i].iters_x = 0; out[i].iters_y = 0; }
+}
+
+thread_local std::string g_err_a = "";
+int fail_a(int code, const std::string& msg) { g_err_a = msg; return code; }
+#define HIP_TRY_A(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail_a(-2, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+// MATLAB linspace(d1, d2, n)
+void linspace_m(double d1, double d2, int n, std::vector<double>& y)
+{
+    y.resize(n);
+    const int n1 = n - 1;
+    for (int k = 0; k <= n1; ++k) y[k] = d1 + (k * (d2 - d1)) / n1;
+    if (n > 0) { y[0] = d1; y[n1] = d2; }
+}
+// quad_walk_no_plots.m:86-99 (initial) / :540-549 (rebuilt)
+void centreline(const std::vector<double>& fs, int step, int ds, int NF, bool initial, std::vector<double>& cl)
+{
+    cl.clear();
+    std::vector<double> lin;
+    if (initial) {
+        for (int k = 0; k < step - ds; ++k) cl.push_back(fs[0] * 1.0);
+        linspace_m(fs[0], fs[1], ds, lin);
+        cl.insert(cl.end(), lin.begin(), lin.end());
+    } else {
+        for (int k = 0; k < step; ++k) cl.push_back(fs[0] * 1.0);
+    }
+    for (int i = 2; i <= NF - 1; ++i) {
+        for (int k = 0; k < step - ds; ++k) cl.push_back(fs[i - 1] * 1.0);
+        linspace_m(fs[i - 1], fs[i], ds, lin);
+        cl.insert(cl.end(), lin.begin(), lin.end());
+    }
+}
+
+}  // namespace
+
+struct ismpc_a_handle {
+    ismpc_a_params p{};
+    DevA c{};
+    int device = 0, slots = 0;
+    ismpc_a_state* prev = nullptr; int prev_cap = 0;     // copy of the state the tick reads
+    std::vector<void*> allocs;
+    std::vector<double> fsx, fsy;
+};
+
+namespace {
+template <typename Tp>
+int upload_a(ismpc_a_handle* h, const std::vector<Tp>& v, const Tp** dst)
+{
+    void* p = nullptr;
+    HIP_TRY_A(hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(Tp)));
+    h->allocs.push_back(p);
+    if (!v.empty()) HIP_TRY_A(hipMemcpy(p, v.data(), v.size() * sizeof(Tp), hipMemcpyHostToDevice));
+    *dst = static_cast<const Tp*>(p);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+const char* ismpc_a_last_error(void) { return g_err_a.c_str(); }
+
+void ismpc_a_params_default(int gait, ismpc_a_params* p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    if (gait == 1) { p->C = 100; p->P = 200; p->step = 50; p->ds = 30; p->Qf = 1e9; }     // quad_walk_no_plots.m:20-45,271
+    else           { p->C = 160; p->P = 320; p->step = 80; p->ds = 50; p->Qf = 1e7; }     // quad_as_bip_no_plots.m:16-39,257
+    p->F = 3; p->n_gait = 100; p->dt = 0.01; p->height = 0.56; p->grav = 9.8; p->w = 0.02;
+    p->disp_forw = 0.5; p->disp_forw_dummy = 0.25; p->disp_L = 0.4;
+}
+
+void ismpc_a_gait_default(int gait, double phi, double disp_A, ismpc_a_gait* g)
+{
+    if (!g) return;
+    g->gait = gait; g->n_gait = 100; g->disp_A = disp_A; g->phi = phi;
+    g->disp_B = 0.259394; g->disp_C = 0.88; g->disp_i = 0.4; g->disp_o = 0.4; g->disp_forw = 0.5;
+}
+
+// trotting/init_quadruped.m:5-184, walking/init_quadruped2.m:5-284 (host; once per run)
+int ismpc_a_plan(const ismpc_a_gait* g, double* foot_plan, double* center)
+{
+    if (!g || !foot_plan || !center || g->n_gait < 16) return fail_a(-1, "bad argument");
+    const int NG = g->n_gait;
+    const double dfd = g->disp_forw / 2, dv = std::min(g->disp_i, g->disp_o), dvd = dv / 2;
+    double xs = g->disp_A * std::cos(g->phi), ys = g->disp_A * std::sin(g->phi);
+    double xsd = g->disp_A * std::cos(g->phi) / 2, ysd = g->disp_A * std::sin(g->phi) / 2;
+    auto clip = [&](double& x, double& y, double vlim, double flim) {
+        if (y > vlim || x > flim) {
+            if (g->phi > std::atan(vlim / flim)) { y = vlim; x = vlim * std::cos(g->phi) / std::sin(g->phi); }
+            else { x = flim; y = flim * std::sin(g->phi) / std::cos(g->phi); }
+        }
+    };
+    clip(xsd, ysd, dvd, dfd);          // first (half) step   :62-81
+    clip(xs, ys, dv, g->disp_forw);    // regular step        :84-102
+    const int rows = NG + 1;           // 1-based rows 1..NG+1 stored at index row-1
+    std::vector<double> fp((size_t)(rows + 8) * 8);
+    auto FP = [&](int r, int col) -> double& { return fp[(size_t)(r - 1) * 8 + (col - 1)]; };
+    for (int r = 1; r <= rows + 7; ++r) {
+        FP(r,1) = 0.0; FP(r,2) = g->disp_B; FP(r,3) = 0.0; FP(r,4) = -g->disp_B;
+        FP(r,5) = g->disp_C; FP(r,6) = -g->disp_B; FP(r,7) = g->disp_C; FP(r,8) = g->disp_B;
+    }
+    auto cross = [&](int r, double& cx, double& cy) {      // intersection of the diagonals BL-FR and BR-FL
+        const double m1 = (FP(r,6) - FP(r,2)) / (FP(r,5) - FP(r,1)), b1 = FP(r,2) - m1 * FP(r,1);
+        const double m2 = (FP(r,8) - FP(r,4)) / (FP(r,7) - FP(r,3)), b2 = FP(r,4) - m2 * FP(r,3);
+        cx = (b2 - b1) / (m1 - m2); cy = m1 * cx + b1;
+    };
+    for (int r = 0; r < NG; ++r) { center[r * 2] = 0.0; center[r * 2 + 1] = 0.0; }
+    center[0] = g->disp_C / 2;
+    int used = NG;
+    if (g->gait == 0) {
+        FP(2,1) = xsd; FP(2,5) = g->disp_C + xsd; FP(2,2) = g->disp_B + ysd; FP(2,6) = -g->disp_B + ysd;
+        for (int j = 3; j <= NG; ++j) {
+            const bool even = (j % 2) == 0;
+            const int mv1 = even ? 1 : 3, mv2 = even ? 5 : 7, hd1 = even ? 3 : 1, hd2 = even ? 7 : 5;
+            FP(j, mv1) = FP(j-1, mv1) + xs; FP(j, mv2) = FP(j-1, mv2) + xs; FP(j, hd1) = FP(j-1, hd1); FP(j, hd2) = FP(j-1, hd2);
+            FP(j, mv1+1) = FP(j-1, mv1+1) + ys; FP(j, mv2+1) = FP(j-1, mv2+1) + ys; FP(j, hd1+1) = FP(j-1, hd1+1); FP(j, hd2+1) = FP(j-1, hd2+1);
+        }
+        for (int k = 2; k <= NG; ++k) cross(k, center[(k-1)*2], center[(k-1)*2+1]);
+    } else {
+        FP(3,7) = g->disp_C + xsd; FP(4,7) = FP(3,7); FP(5,7) = FP(3,7);
+        FP(2,3) = FP(1,3); FP(3,3) = FP(1,3); FP(4,3) = FP(3,3); FP(5,3) = FP(4,3) + xsd;
+        FP(3,8) = g->disp_B + ysd; FP(4,8) = FP(3,8); FP(5,8) = FP(3,8);
+        FP(2,4) = FP(1,4); FP(3,4) = FP(1,4); FP(4,4) = FP(3,4); FP(5,4) = FP(4,4) + ysd;
+        for (int j = 6; j <= NG; j += 8) {
+            for (int cc = 0; cc < 2; ++cc) {
+                const double st = cc == 0 ? xs : ys;
+                const int BL = 1 + cc, BR = 3 + cc, FR = 5 + cc, FL = 7 + cc;
+                FP(j,FR) = FP(j-1,FR); FP(j+1,FR) = FP(j,FR) + st; for (int k = 2; k <= 7; ++k) FP(j+k,FR) = FP(j+1,FR);
+                FP(j,BL) = FP(j-1,BL); FP(j+1,BL) = FP(j,BL); FP(j+2,BL) = FP(j,BL); FP(j+3,BL) = FP(j+2,BL) + st;
+                for (int k = 4; k <= 7; ++k) FP(j+k,BL) = FP(j+3,BL);
+                FP(j,FL) = FP(j-1,FL); for (int k = 1; k <= 4; ++k) FP(j+k,FL) = FP(j,FL);
+                FP(j+5,FL) = FP(j+4,FL) + st; FP(j+6,FL) = FP(j+5,FL); FP(j+7,FL) = FP(j+5,FL);
+                FP(j,BR) = FP(j-1,BR); for (int k = 1; k <= 6; ++k) FP(j+k,BR) = FP(j,BR);
+                FP(j+7,BR) = FP(j+6,BR) + st;
+            }
+            used = std::max(used, j + 7);
+        }
+        used = std::min(used, NG + 1);
+        for (int j = 1; j <= NG - 4; j += 8) {
+            for (int k = 0; k <= 6; k += 2) cross(j + k, center[(j+k-1)*2], center[(j+k-1)*2+1]);
+            for (int k = 1; k <= 7; k += 2) { center[(j+k-1)*2] = center[(j+k-2)*2]; center[(j+k-1)*2+1] = center[(j+k-2)*2+1]; }
+        }
+    }
+    std::memcpy(foot_plan, fp.data(), sizeof(double) * (size_t)used * 8);
+    return used;
+}
+
+int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, ismpc_a_handle** out)
+{
+    if (!p || !center || !out) return fail_a(-1, "null argument");
+    *out = nullptr;
+    if (p->C < 2 || p->F < 1 || p->F > MAXF || p->C + p->F > T || p->P <= p->C || p->step < 2 || p->ds < 2 || p->ds >= p->step ||
+        p->n_gait < p->F + 2 || !(p->dt > 0) || !(p->height > 0) || !(p->Qf > 0) || !(p->w >= 0))
+        return fail_a(-1, "unsupported parameters (need 2 <= C, C + F <= 256, 1 <= F <= 8, P > C, 2 <= ds < step)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail_a(-2, "no HIP device visible: the ISMPC hot path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail_a(-1, "device ordinal out of range");
+    ismpc_a_handle* h = new (std::nothrow) ismpc_a_handle();
+    if (!h) return fail_a(-3, "out of host memory");
+    h->p = *p; h->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete h; return fail_a(-2, "hipSetDevice failed"); }
+    DevA& c = h->c;
+    c.C = p->C; c.P = p->P; c.F = p->F; c.step = p->step; c.ds = p->ds; c.n_gait = p->n_gait;
+    c.dt = p->dt; c.eta = std::sqrt(p->grav / p->height); c.w = p->w; c.Qf = p->Qf;
+    c.disp_forw = p->disp_forw; c.disp_forw_dummy = p->disp_forw_dummy; c.disp_L = p->disp_L;
+    c.ldq = p->C + p->F + 2; c.max_iter = 20 * (p->C + p->F) + 200;
+    const double eta = c.eta, dt = c.dt;
+    const double ch = std::cosh(eta * dt), sh = std::sinh(eta * dt);                           // :67-71
+    const double Au[9] = { ch, sh / eta, 1 - ch, eta * sh, ch, -eta * sh, 0, 0, 1 };
+    const double Bu[3] = { dt - sh / eta, 1 - ch, dt };
+    std::memcpy(c.Au, Au, sizeof(Au)); std::memcpy(c.Bu, Bu, sizeof(Bu));
+    // stability row (:233-238) and tail weights (:229-231)
+    const double lambda = std::exp(-eta * dt);
+    std::vector<double> a(p->C), PA(p->C + 1, 0.0), wt(p->P - p->C);
+    double aa = 0.0;
+    for (int i = 0; i < p->C; ++i) {
+        a[i] = (1 / eta) * (1 - lambda) / (1 - std::pow(lambda, p->C)) * std::exp(-eta * dt * i) - dt * 1.0 * std::exp(-eta * dt * p->C);
+        PA[i + 1] = PA[i] + a[i]; aa += a[i] * a[i];
+    }
+    double sumw = 0.0;
+    for (int i = p->C + 1; i <= p->P; ++i) { wt[i - (p->C + 1)] = std::exp(-eta * dt * i) * (1 - std::exp(-eta * dt)); sumw += wt[i - (p->C + 1)]; }
+    c.wP = std::exp(-eta * dt * p->P); c.sumw = sumw + c.wP; c.aa = aa;
+    h->fsx.resize(p->n_gait); h->fsy.resize(p->n_gait);
+    for (int i = 0; i < p->n_gait; ++i) { h->fsx[i] = center[i * 2]; h->fsy[i] = center[i * 2 + 1]; }
+    std::vector<double> clx0, cly0, clx1, cly1;
+    centreline(h->fsx, p->step, p->ds, p->n_gait, true, clx0);  centreline(h->fsy, p->step, p->ds, p->n_gait, true, cly0);
+    centreline(h->fsx, p->step, p->ds, p->n_gait, false, clx1); centreline(h->fsy, p->step, p->ds, p->n_gait, false, cly1);
+    c.ncl = (int)std::min(clx0.size(), clx1.size());
+    int rc = upload_a(h, a, &c.a);
+    if (!rc) rc = upload_a(h, PA, &c.PA);
+    if (!rc) rc = upload_a(h, wt, &c.wtail);
+    if (!rc) rc = upload_a(h, h->fsx, &c.fsx);
+    if (!rc) rc = upload_a(h, h->fsy, &c.fsy);
+    if (!rc) rc = upload_a(h, clx0, &c.clx0);
+    if (!rc) rc = upload_a(h, cly0, &c.cly0);
+    if (!rc) rc = upload_a(h, clx1, &c.clx1);
+    if (!rc) rc = upload_a(h, cly1, &c.cly1);
+    if (!rc) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) rc = fail_a(-2, "hipGetDeviceProperties failed");
+        else {
+            h->slots = prop.multiProcessorCount * 4;          // persistent grid: 4 workgroups per CU
+            void* sc = nullptr;
+            if (hipMalloc(&sc, (size_t)h->slots * c.ldq * c.ldq * sizeof(double)) != hipSuccess) rc = fail_a(-3, "scratch allocation failed");
+            else { h->allocs.push_back(sc); c.scratch = static_cast<double*>(sc); }
+        }
+    }
+    if (rc) { ismpc_a_destroy(h); return rc; }
+    *out = h;
+    return 0;
+}
+
+void ismpc_a_destroy(ismpc_a_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->prev) (void)hipFree(h->prev);
+    delete h;
+}
+
+int ismpc_a_initial_state(const ismpc_a_handle* h, double disp_C, ismpc_a_state* st)
+{
+    if (!h || !st) return fail_a(-1, "null argument");
+    std::memset(st, 0, sizeof(*st));
+    st->x = disp_C / 2; st->xz = disp_C / 2;                  // :52-57
+    st->cur_x = h->fsx[0]; st->cur_y = h->fsy[0];             // :58-59
+    st->fc = 1; st->j = 1;
+    return 0;
+}
+
+int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const double* push_dev,
+                              ismpc_a_out* out_dev, void* stream)
+{
+    if (!h || batch < 0 || (batch > 0 && !state_dev)) return fail_a(-1, "bad argument");
+    if (batch == 0) return 0;
+    HIP_TRY_A(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (batch > h->prev_cap) {
+        if (h->prev) (void)hipFree(h->prev);
+        h->prev = nullptr; h->prev_cap = 0;
+        HIP_TRY_A(hipMalloc((void**)&h->prev, sizeof(ismpc_a_state) * (size_t)batch));
+        h->prev_cap = batch;
+    }
+    HIP_TRY_A(hipMemcpyAsync(h->prev, state_dev, sizeof(ismpc_a_state) * (size_t)batch, hipMemcpyDeviceToDevice, s));
+    if (out_dev) hipLaunchKernelGGL(ismpc_a_clear_out, dim3((batch + 255) / 256), dim3(256), 0, s, out_dev, batch);
+    const int grid = std::min(2 * batch, h->slots);
+    hipLaunchKernelGGL(ismpc_a_tick_kernel, dim3(grid), dim3(T), 0, s, h->c, (const ismpc_a_state*)h->prev, state_dev, push_dev, out_dev, batch);
+    HIP_TRY_A(hipGetLastError());
+    return 0;
+}
+
+int ismpc_a_rollout_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, int ticks, ismpc_a_out* out_traj_dev, void* stream)
+{
+    if (!h || batch < 0 || ticks < 0 || (batch > 0 && !state_dev)) return fail_a(-1, "bad argument");
+    for (int t = 0; t < ticks; ++t) {
+        int rc = ismpc_a_tick_batch_device(h, batch, state_dev, nullptr, out_traj_dev ? out_traj_dev + (size_t)t * batch : nullptr, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"
