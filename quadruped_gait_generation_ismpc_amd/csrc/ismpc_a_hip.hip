@@ -35,7 +35,7 @@ constexpr int MAXF = 8;
 constexpr int QCAP = 264;              // capacity of the working set (>= C + F + 1)
 
 struct DevA {
-    int C, P, F, step, ds, n_gait, ncl, ldq, max_iter;
+    int C, P, F, step, ds, n_gait, ncl, ldq, max_iter, sinv_in_lds;
     double dt, eta, w, Qf, disp_forw, disp_forw_dummy, disp_L, aa, wP, sumw;
     double Au[9], Bu[3];
     const double *a, *PA, *wtail;      // stability row, its prefix sums PA[i] = sum_{k<i} a_k, tail weights (index i-(C+1))
@@ -86,6 +86,19 @@ __device__ __forceinline__ double block_scan_incl(Shared& s, double v, int tid)
     __syncthreads();
     double add = 0.0;
     for (int wv = 0; wv < wave; ++wv) add += s.wsum[wv];
+    __syncthreads();
+    return p + add;
+}
+// inclusive prefix sum plus the workgroup total
+__device__ __forceinline__ double block_scan_incl_tot(Shared& s, double v, int tid, double& tot)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const double p = wave_scan_up(v);
+    if (lane == 63) s.wsum[wave] = p;
+    __syncthreads();
+    double add = 0.0;
+    for (int wv = 0; wv < wave; ++wv) add += s.wsum[wv];
+    tot = ((s.wsum[0] + s.wsum[1]) + s.wsum[2]) + s.wsum[3];
     __syncthreads();
     return p + add;
 }
@@ -191,16 +204,23 @@ __device__ __forceinline__ void build_direction(Shared& s, const DevA& c, int ti
         }
     }
     // note: two different active ZMP rows never share an index, and the extra row is not active: no write race
-    const double cetot = block_sum(s, ce, tid);
-    // footstep parts: fixed-order reduction (bit reproducible)
-    for (int k = 1; k <= F; ++k) {
-        const double tot = block_sum(s, fpart[k], tid);
-        if (tid == 0) s.zf[k] = tot / c.Qf;
+    // stability coefficient and footstep parts: one wave scan each, ONE barrier, fixed-order combine (bit reproducible)
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const double pe = wave_scan_up(ce);
+        if (lane == 63) s.zfpart[wave][0] = pe;
+        for (int k = 1; k <= F; ++k) {
+            const double pk = wave_scan_up(fpart[k]);
+            if (lane == 63) s.zfpart[wave][k] = pk;
+        }
     }
+    __syncthreads();
+    const double cetot = ((s.zfpart[0][0] + s.zfpart[1][0]) + s.zfpart[2][0]) + s.zfpart[3][0];
+    if (tid >= 1 && tid <= F) s.zf[tid] = (((s.zfpart[0][tid] + s.zfpart[1][tid]) + s.zfpart[2][tid]) + s.zfpart[3][tid]) / c.Qf;
     // suffix sum of the impulses = total - exclusive prefix
     const double v = (tid < C) ? s.imp[tid] : 0.0;
-    const double incl = block_scan_incl(s, v, tid);
-    const double tot = block_sum(s, v, tid);
+    double tot;
+    const double incl = block_scan_incl_tot(s, v, tid, tot);
     if (tid < C) s.zu[tid] = (tot - (incl - v)) + cetot * s.a[tid];
     __syncthreads();
 }
@@ -226,9 +246,10 @@ void ismpc_a_tick_kernel(const DevA c, const ismpc_a_state* __restrict__ state_i
                          const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch)
 {
     __shared__ Shared s;
+    extern __shared__ double sinv_lds[];            // ldq x ldq when the launch asked for it (c.sinv_in_lds)
     const int tid = threadIdx.x;
     const int C = c.C, F = c.F, P = c.P;
-    double* Sinv = c.scratch + (size_t)blockIdx.x * c.ldq * c.ldq;
+    double* Sinv = c.sinv_in_lds ? sinv_lds : c.scratch + (size_t)blockIdx.x * c.ldq * c.ldq;
     const int ldq = c.ldq;
 
     for (int work = blockIdx.x; work < 2 * batch; work += gridDim.x) {
@@ -345,6 +366,7 @@ void ismpc_a_tick_kernel(const DevA c, const ismpc_a_state* __restrict__ state_i
                         __syncthreads();
                         if (tid < q) {
                             double acc = 0.0;
+#pragma unroll 8
                             for (int k = 0; k < q; ++k) acc += Sinv[(size_t)k * ldq + tid] * s.r[k];
                             s.dp[tid] = acc * s.act_sgn[tid];
                         }
@@ -382,6 +404,7 @@ void ismpc_a_tick_kernel(const DevA c, const ismpc_a_state* __restrict__ state_i
                     // r = S^-1 d
                     double racc = 0.0;
                     if (tid < q) {
+#pragma unroll 8
                         for (int k = 0; k < q; ++k) racc += Sinv[(size_t)k * ldq + tid] * s.dp[k];
                         s.r[tid] = racc;
                     }
@@ -411,6 +434,7 @@ void ismpc_a_tick_kernel(const DevA c, const ismpc_a_state* __restrict__ state_i
                         const double ig = 1.0 / gamma;
                         if (tid < q) {
                             const double rj = s.r[tid];
+#pragma unroll 8
                             for (int k = 0; k < q; ++k) Sinv[(size_t)k * ldq + tid] += s.r[k] * rj * ig;
                             Sinv[(size_t)q * ldq + tid] = -rj * ig;
                             Sinv[(size_t)tid * ldq + q] = -rj * ig;
@@ -431,6 +455,7 @@ void ismpc_a_tick_kernel(const DevA c, const ismpc_a_state* __restrict__ state_i
                         __syncthreads();
                         if (tid < q && tid != l) {
                             const double cj = s.r[tid] / piv;
+#pragma unroll 8
                             for (int k = 0; k < q; ++k) if (k != l) Sinv[(size_t)k * ldq + tid] -= s.r[k] * cj;
                         }
                         __syncthreads();
@@ -670,7 +695,15 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     c.C = p->C; c.P = p->P; c.F = p->F; c.step = p->step; c.ds = p->ds; c.n_gait = p->n_gait;
     c.dt = p->dt; c.eta = std::sqrt(p->grav / p->height); c.w = p->w; c.Qf = p->Qf;
     c.disp_forw = p->disp_forw; c.disp_forw_dummy = p->disp_forw_dummy; c.disp_L = p->disp_L;
-    c.ldq = p->C + p->F + 2; c.max_iter = 20 * (p->C + p->F) + 200;
+    c.ldq = (p->C + p->F + 2) | 1;                        // odd leading dimension: conflict-free LDS columns
+    c.max_iter = 20 * (p->C + p->F) + 200;
+    // S^-1 lives in an L2-resident scratch slab (4 workgroups per CU); ISMPC_A_SINV=lds keeps it in LDS instead when it
+    // fits next to the static block (then 1 workgroup per CU).  Measured on MI355X (walk, C=100, batch 16 384):
+    // scratch 2.8e5 ticks/s, LDS 2.0e5 ticks/s -- the kernel is barrier-latency bound, concurrency wins.
+    c.sinv_in_lds = 0;
+    if (const char* e = std::getenv("ISMPC_A_SINV")) {
+        if (!std::strcmp(e, "lds") && (size_t)c.ldq * c.ldq * sizeof(double) + sizeof(Shared) + 1024 <= 160u * 1024u) c.sinv_in_lds = 1;
+    }
     const double eta = c.eta, dt = c.dt;
     const double ch = std::cosh(eta * dt), sh = std::sinh(eta * dt);                           // :67-71
     const double Au[9] = { ch, sh / eta, 1 - ch, eta * sh, ch, -eta * sh, 0, 0, 1 };
@@ -706,11 +739,15 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) rc = fail_a(-2, "hipGetDeviceProperties failed");
         else {
-            h->slots = prop.multiProcessorCount * 4;          // persistent grid: 4 workgroups per CU
+            h->slots = prop.multiProcessorCount * (c.sinv_in_lds ? 1 : 4);   // persistent grid: workgroups per CU
             void* sc = nullptr;
             if (hipMalloc(&sc, (size_t)h->slots * c.ldq * c.ldq * sizeof(double)) != hipSuccess) rc = fail_a(-3, "scratch allocation failed");
             else { h->allocs.push_back(sc); c.scratch = static_cast<double*>(sc); }
         }
+    }
+    if (!rc && c.sinv_in_lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ismpc_a_tick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)c.ldq * c.ldq * sizeof(double))) != hipSuccess) c.sinv_in_lds = 0, h->slots *= 4;
     }
     if (rc) { ismpc_a_destroy(h); return rc; }
     *out = h;
@@ -752,7 +789,7 @@ int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state
     HIP_TRY_A(hipMemcpyAsync(h->prev, state_dev, sizeof(ismpc_a_state) * (size_t)batch, hipMemcpyDeviceToDevice, s));
     if (out_dev) hipLaunchKernelGGL(ismpc_a_clear_out, dim3((batch + 255) / 256), dim3(256), 0, s, out_dev, batch);
     const int grid = std::min(2 * batch, h->slots);
-    hipLaunchKernelGGL(ismpc_a_tick_kernel, dim3(grid), dim3(T), 0, s, h->c, (const ismpc_a_state*)h->prev, state_dev, push_dev, out_dev, batch);
+    hipLaunchKernelGGL(ismpc_a_tick_kernel, dim3(grid), dim3(T), h->c.sinv_in_lds ? (size_t)h->c.ldq * h->c.ldq * sizeof(double) : 0, s, h->c, (const ismpc_a_state*)h->prev, state_dev, push_dev, out_dev, batch);
     HIP_TRY_A(hipGetLastError());
     return 0;
 }

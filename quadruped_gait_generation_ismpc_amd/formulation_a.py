@@ -98,7 +98,7 @@ class GaitGenerator:
         self._h = h
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _l is not None:
             _l().ismpc_a_destroy(self._h); self._h = None
 
     def __del__(self):

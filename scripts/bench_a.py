@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Formulation A throughput (BASELINE configs 4-5 family): one tick over a batch of perturbed nominal
+instances.  Not the headline bench (bench.py); numbers go to DESIGN.md.
+usage: python scripts/bench_a.py [walk_C150|walk_C100|trot_C160] [batch] [steps] [--cpu]"""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import quadruped_gait_generation_ismpc_amd as q
+from quadruped_gait_generation_ismpc_amd import formulation_a as FA
+
+name = sys.argv[1] if len(sys.argv) > 1 else "walk_C150"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+z = np.load(os.path.join(ROOT, "tests", "golden", f"prerollA_{name}.npz"))
+tab = z["state"].view(FA.STATE_A).reshape(-1)
+kind = int(z["gait"]); g = FA.default_gait(kind, float(z["phi"]), float(z["disp_A"]))
+fp, ce = FA.plan(g)
+p = FA.default_params(kind, C=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
+gen = FA.GaitGenerator(p, ce)
+rng = np.random.Generator(np.random.Philox(key=20261003))
+jj = rng.integers(0, len(tab), batch)
+st0 = tab[jj].copy()
+push = np.stack([rng.uniform(-0.03, 0.03, batch), rng.uniform(-0.05, 0.05, batch)], 1)
+d0 = q.to_device(st0); d = d0.clone(); dpush = torch.from_numpy(push.copy()).cuda()
+out = gen.tick_torch(d, dpush); torch.cuda.synchronize()
+o = q.from_device(out, FA.OUT_A)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter(); e0.record()
+for _ in range(steps):
+    d.copy_(d0); out = gen.tick_torch(d, dpush)
+e1.record(); torch.cuda.synchronize(); el = time.perf_counter() - t0
+res = {"workload": name, "batch": batch, "steps": steps, "ticks_per_s": batch * steps / el, "ms_per_step": 1e3 * el / steps,
+       "event_ms_per_step": e0.elapsed_time(e1) / steps, "status_nonzero": int((o["status"] != 0).sum()),
+       "iters_mean": float((o["iters_x"] + o["iters_y"]).mean() / 2), "iters_max": int(max(o["iters_x"].max(), o["iters_y"].max())),
+       "active_mean": float(((o["active"] & 0xffff) + (o["active"] >> 16)).mean() / 2), "active_max": int(max((o["active"] & 0xffff).max(), (o["active"] >> 16).max()))}
+if "--cpu" in sys.argv:
+    from oracle import oracle_a as A
+    n = 200
+    sim = A.SimA(A.gait(kind, float(z["phi"]), float(z["disp_A"])), A.params(kind, C_=int(z["C"]), P=int(z["P"]), F=int(z["F"])), backend="ref" if A.O.have_ref() else "gi")
+    # replay the nominal loop: same per-tick QPs as the table rows (cold start each tick, like the reference)
+    t0 = time.perf_counter(); sim.run(n); el = time.perf_counter() - t0
+    res["cpu_ticks_per_s"] = n / el; res["cpu_backend"] = sim.backend
+print(json.dumps(res))
