@@ -30,6 +30,7 @@
 #include <string>
 #include <vector>
 #include <new>
+#include <algorithm>
 #include "ismpc_tables.hpp"
 
 namespace {
@@ -46,6 +47,9 @@ struct DevConst {
     // affine form of the vertical stage (ismpc_tables.hpp)
     const double *vtab, *tz, *tg, *dU, *SdU, *Wt, *SW;
     int flat;
+    // inequality fallback (0 <= S u <= 1e4 active)
+    const double *HSt, *SHSt;
+    int* zflag;                       // id of the last launch that deferred an instance to the fallback kernel
 };
 
 // ---- wavefront (64 lanes) primitives: DPP, no LDS crossbar (ds_bpermute) on the critical path ----
@@ -524,16 +528,193 @@ template <int R> __device__ __forceinline__ void loadR(const double* p, double (
     }
 }
 
+// ---- vertical QP with active inequality rows (MPCSolver.cpp:158-160: 0 <= S_bar_z u <= 1e4), rare path ----
+// Dual active-set in range-space form over the inequality rows only: the equalities are already inside the
+// reduced inverse P_p = (I - W_p E_p') Hinv, so with p_k = P_p S_k' and g_k = S p_k (rows of the HSt / SHSt tables,
+// pattern folded in with Wt / SW) the Gram matrix of the working set is G[j][k] = g_k[row_j].  Working set
+// <= QZ rows, one lane per entry, its row of G^-1 in that lane's registers.
+constexpr int QZ = 16;
+__device__ __forceinline__ double readlane_dyn(double v, int l)
+{
+    const int ll = __builtin_amdgcn_readfirstlane(l);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), ll), __builtin_amdgcn_readlane(__double2loint(v), ll));
+}
+__device__ __forceinline__ int readlane_dyn(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+__device__ __forceinline__ double wave_allmax(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_allmin(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
 template <int R>
-__global__ __launch_bounds__(256)
-void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
-                       ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame)
+__device__ __forceinline__ double sample_at(const double (&v)[R], int k)     // v at sample k (k wave-uniform)
+{
+    const int owner = k / R, slot = k - owner * R;
+    double x = v[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) if (slot == r) x = v[r];
+    return readlane_dyn(x, owner);
+}
+template <int R>
+__device__ __forceinline__ void z_fetch(const DevConst& c, int row, int n0, int pat, int elo, int ne, double (&pc)[R], double (&gc)[R])
 {
     constexpr int NT = ismpc::Tables::NT;
-    const int lane = threadIdx.x & 63;
-    const int gi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (gi >= batch) return;
+    loadR<R>(c.HSt + (size_t)row * NT + n0, pc); loadR<R>(c.SHSt + (size_t)row * NT + n0, gc);
+    for (int e = 0; e < ne; ++e) {
+        const double ue = c.HSt[(size_t)row * NT + elo + e];
+        double wv[R], sv[R];
+        loadR<R>(c.Wt + ((size_t)pat * c.Fmax + e) * NT + n0, wv); loadR<R>(c.SW + ((size_t)pat * c.Fmax + e) * NT + n0, sv);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { pc[r] -= wv[r] * ue; gc[r] -= sv[r] * ue; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int n = n0 + r; if (n >= elo && n < elo + ne) pc[r] = 0.0; }
+}
+// returns the iteration count; updates u, su in place
+template <int R>
+__device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double (&u)[R], double (&su)[R], int& status)
+{
     const int N = c.N;
+    int elo = 0, ne = 0;
+    if (pat < c.npat) { elo = c.e_lo[pat]; ne = c.ne[pat]; }
+    const double tol_lo = 1e-11 * fmax(1.0, fabs(c.z_lo)), tol_hi = 1e-11 * fmax(1.0, fabs(c.z_hi));
+    int arow = -1; double asg = 0.0, amu = 0.0;
+    double Srow[QZ];
+#pragma unroll
+    for (int k = 0; k < QZ; ++k) Srow[k] = 0.0;
+    bool sact[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) sact[r] = false;
+    int q = 0, its = 0;
+    for (;;) {
+        // ---- most violated free row
+        double best = 0.0; int code = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = n0 + r;
+            if (n < N && !sact[r]) {
+                const double vl = c.z_lo - su[r], vh = su[r] - c.z_hi;
+                if (vl > tol_lo && vl > best) { best = vl; code = 2 * n; }
+                if (vh > tol_hi && vh > best) { best = vh; code = 2 * n + 1; }
+            }
+        }
+        const double vmax = wave_allmax(best);
+        if (!(vmax > 0.0)) break;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(best == vmax);
+        code = readlane_dyn(code, (int)__builtin_ctzll(m));
+        const int row = code >> 1;
+        const double sg = (code & 1) ? -1.0 : 1.0;
+        if (q >= QZ) { status |= ISMPC_ST_Z_FAILED; break; }
+        double pc[R], gc[R];
+        z_fetch<R>(c, row, n0, pat, elo, ne, pc, gc);
+        const double npn = sample_at<R>(gc, row);
+        double mu_p = 0.0;
+        bool fail = false;
+        for (;;) {
+            if (++its > 8 * QZ) { fail = true; break; }
+            const double srow = sample_at<R>(su, row);
+            const double sviol = sg > 0.0 ? srow - c.z_lo : c.z_hi - srow;
+            // d_j = sg * asg_j * g_row[arow_j]
+            double dj = 0.0;
+            for (int j = 0; j < q; ++j) {
+                const double val = sample_at<R>(gc, readlane_dyn(arow, j));
+                if (lane == j) dj = sg * asg * val;
+            }
+            double rj = 0.0;
+#pragma unroll
+            for (int k = 0; k < QZ; ++k) if (k < q) rj += Srow[k] * readlane_dyn(dj, k);
+            if (lane >= q) rj = 0.0;
+            const double gamma = npn - wave_sum((lane < q) ? dj * rj : 0.0);
+            const double tc = (lane < q && rj > 0.0) ? amu / rj : INFINITY;
+            const double t1 = wave_allmin(tc);
+            const double t2 = (gamma > 1e-12 * npn) ? -sviol / gamma : INFINITY;
+            const double t = fmin(t1, t2);
+            if (!(t < INFINITY)) { fail = true; break; }
+            if (t2 < INFINITY) {
+                // z = P (n+ - N r): columns of the active rows, coefficient -r_j asg_j, plus the new one
+                double zu[R], zs[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { zu[r] = sg * pc[r]; zs[r] = sg * gc[r]; }
+                for (int j = 0; j < q; ++j) {
+                    const double cf = -readlane_dyn(rj * asg, j);
+                    double pj[R], gj[R];
+                    z_fetch<R>(c, readlane_dyn(arow, j), n0, pat, elo, ne, pj, gj);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { zu[r] = fma(cf, pj[r], zu[r]); zs[r] = fma(cf, gj[r], zs[r]); }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) { u[r] = fma(t, zu[r], u[r]); su[r] = fma(t, zs[r], su[r]); }
+            }
+            if (lane < q) amu -= t * rj;
+            mu_p += t;
+            if (t2 < INFINITY && t == t2) {
+                // ---- add: border update of G^-1
+                const double ig = 1.0 / gamma;
+#pragma unroll
+                for (int k = 0; k < QZ; ++k) {
+                    if (k < q) {
+                        const double rk = readlane_dyn(rj, k);
+                        if (lane < q) Srow[k] = fma(rj * ig, rk, Srow[k]);
+                        if (lane == q) Srow[k] = -rk * ig;
+                    } else if (k == q) {
+                        if (lane < q) Srow[k] = -rj * ig;
+                        if (lane == q) Srow[k] = ig;
+                    }
+                }
+                if (lane == q) { arow = row; asg = sg; amu = mu_p; }
+#pragma unroll
+                for (int r = 0; r < R; ++r) if (n0 + r == row) sact[r] = true;
+                ++q;
+                break;
+            }
+            // ---- drop entry l (first lane attaining t1): Schur update, last entry moves into slot l
+            const int l = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(tc == t1));
+            const int last = q - 1;
+            const int drow = readlane_dyn(arow, l);
+            double coll = 0.0, clast = 0.0;
+#pragma unroll
+            for (int k = 0; k < QZ; ++k) { if (k == l) coll = Srow[k]; if (k == last) clast = Srow[k]; }
+            const double piv = readlane_dyn(coll, l);
+#pragma unroll
+            for (int k = 0; k < QZ; ++k) if (k < q) Srow[k] -= coll * readlane_dyn(Srow[k], l) / piv;   // uses row l before it moves
+            if (l != last) {
+#pragma unroll
+                for (int k = 0; k < QZ; ++k) if (k == last) clast = Srow[k];
+#pragma unroll
+                for (int k = 0; k < QZ; ++k) {
+                    const double vl_ = readlane_dyn(Srow[k], last);
+                    if (lane == l) Srow[k] = vl_;
+                }
+#pragma unroll
+                for (int k = 0; k < QZ; ++k) if (k == l) Srow[k] = (lane == l) ? readlane_dyn(clast, last) : clast;
+                const int ar = readlane_dyn(arow, last); const double as_ = readlane_dyn(asg, last), am = readlane_dyn(amu, last);
+                if (lane == l) { arow = ar; asg = as_; amu = am; }
+            }
+            if (lane == last) { arow = -1; asg = 0.0; amu = 0.0; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (n0 + r == drow) sact[r] = false;
+            --q;
+        }
+        if (fail) { status |= ISMPC_ST_Z_FAILED; break; }
+    }
+    return its;
+}
+
+template <int R, bool FB>
+__device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi, const int lane,
+                                                 const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
+                                                 ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
+                                                 int rollout_frame, unsigned char* zmark, int launch_id)
+{
+    constexpr int NT = ismpc::Tables::NT;
+    const int N = c.N;
+    bool deferred = false;                            // FB == false: an instance with active inequality rows is left to the fallback kernel
     const double dt = c.dt;
     const ismpc_tick_in* rec = ((rollout_frame >= 0) ? state_rw : in_ro) + gi;
     const Walk w = load_walk(c, rec, rollout_frame);
@@ -543,7 +724,7 @@ void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
     int status = gate_tick(c, w, idx);
     double o_x = x0, o_y = y0, o_z = z0, o_xd = xd0, o_yd = yd0, o_zd = zd0;
     double uz0 = 0.0, ux0 = 0.0, uy0 = 0.0;
-    int itx = 0, ity = 0;
+    int itx = 0, ity = 0, zits = 0;
     const int n0 = lane * R;                          // this lane owns samples n0 .. n0+R-1 (tables are zero past N)
     double u[R], a[R];
 #pragma unroll
@@ -597,11 +778,19 @@ void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
         for (int r = 0; r < R; ++r) {
             const int n = n0 + r;
             viol = viol || (n < N && (su[r] < zlo_t || su[r] > zhi_t));         // MPCSolver.cpp:158-160, beyond rounding
+        }
+        const bool anyviol = __builtin_amdgcn_ballot_w64(viol) != 0;
+        if (anyviol) {
+            status |= ISMPC_ST_Z_INEQ_ACTIVE;
+            if constexpr (FB) zits = z_active_set<R>(c, lane, n0, pat, u, su, status);
+            else deferred = true;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
             const double zpos = su[r] + fma(tz[r], zd0, z0) + tg[r];            // S u + T_bar_z s + T_bar_g_z
             const double zacc = (1.0 / c.mass) * u[r] - c.g;
             lam[r] = (c.g + zacc) / zpos;                                       // MPCSolver.cpp:306
         }
-        if (__builtin_amdgcn_ballot_w64(viol) != 0) status |= ISMPC_ST_Z_INEQ_ACTIVE;
         uz0 = bcast0(u[0]);
         o_z = z0 + dt * zd0;                                                    // MPCSolver.cpp:274-278
         o_zd = zd0 + (dt / c.mass) * uz0 - dt * c.g;
@@ -732,7 +921,7 @@ void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
     // ---- 80-byte output record: lanes 0..9 store one 8-byte word each
     {
         double word = 0.0;
-        const long long packed = (long long)(unsigned)status | ((long long)(unsigned)((itx & 255) | ((ity & 255) << 8)) << 32);
+        const long long packed = (long long)(unsigned)status | ((long long)(unsigned)((itx & 255) | ((ity & 255) << 8) | ((zits & 255) << 16)) << 32);
         switch (lane) {
             case 0: word = o_x; break;  case 1: word = o_y; break;  case 2: word = o_z; break;
             case 3: word = o_xd; break; case 4: word = o_yd; break; case 5: word = o_zd; break;
@@ -759,7 +948,11 @@ void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
         }
     }
     // ---- closed loop: feed back (Controller.cpp:346-348) and advance counters (:503-504)
-    if (rollout_frame >= 0 && lane == 0) {
+    if constexpr (!FB) {
+        if (zmark && lane == 0) zmark[gi] = deferred ? 1 : 0;
+        if (deferred && lane == 0) atomicMax(c.zflag, launch_id);
+    }
+    if (rollout_frame >= 0 && lane == 0 && !deferred) {
         ismpc_tick_in* st = state_rw + gi;
         st->com_pos[0] = o_x; st->com_pos[1] = o_y; st->com_pos[2] = o_z;
         st->com_vel[0] = o_xd; st->com_vel[1] = o_yd; st->com_vel[2] = o_zd;
@@ -769,6 +962,33 @@ void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
         st->mpc_iter = (int)floor(ctl * c.cdt / c.dt);
         st->footstep_counter = w.fc;
     }
+}
+
+
+template <int R>
+__global__ __launch_bounds__(256)
+void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
+                       ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
+                       unsigned char* zmark, int launch_id)
+{
+    const int lane = threadIdx.x & 63;
+    const int gi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (gi >= batch) return;
+    tick_affine_body<R, false>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+}
+
+// Second launch of every tick: exits at once unless the first one deferred instances (active inequality rows).
+template <int R>
+__global__ __launch_bounds__(256)
+void ismpc_tick_affine_fallback(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
+                                ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
+                                unsigned char* zmark, int launch_id)
+{
+    if (*c.zflag != launch_id) return;
+    const int lane = threadIdx.x & 63;
+    const int wave0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int gi = wave0; gi < batch; gi += gridDim.x * 4)
+        if (zmark[gi]) tick_affine_body<R, true>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
 }
 
 // ------------------------------------------------------------------------
@@ -790,6 +1010,7 @@ struct ismpc_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false; bool timed_pending = false; double last_ms = 0.0;
     int force_waves = 0;      // dense path: 4, 8 or 16 wavefronts per workgroup (0 = 16)
+    unsigned char* zmark = nullptr; int zmark_cap = 0; int launch_id = 0; bool z_fallback = true;
     bool dense_path = false;  // true: per-tick MFMA solve (ismpc_tick_dense); false: affine tables (ismpc_tick_affine)
 };
 
@@ -813,15 +1034,29 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
     if (batch <= 0) return ISMPC_OK;
     const int R = (h->c.N + 63) / 64;
     if (!h->dense_path) {
-        // fast path: wavefront per instance, 4 per workgroup
+        // fast path: wavefront per instance, 4 per workgroup; then the (normally empty) inequality fallback
         const dim3 grid((batch + 3) / 4), block(256);
+        if (h->z_fallback && batch > h->zmark_cap) {
+            if (h->zmark) (void)hipFree(h->zmark);
+            h->zmark = nullptr; h->zmark_cap = 0;
+            HIP_TRY(hipMalloc((void**)&h->zmark, (size_t)batch));
+            h->zmark_cap = batch;
+        }
+        unsigned char* zm = h->z_fallback ? h->zmark : nullptr;
+        const int lid = ++h->launch_id;
+        const dim3 fgrid(std::min((batch + 3) / 4, 256));
+#define ISMPC_AFF(RR) do { \
+        hipLaunchKernelGGL(ismpc_tick_affine<RR>, grid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); \
+        if (zm) hipLaunchKernelGGL(ismpc_tick_affine_fallback<RR>, fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); \
+    } while (0)
         switch (R) {
-            case 1: hipLaunchKernelGGL(ismpc_tick_affine<1>, grid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
-            case 2: hipLaunchKernelGGL(ismpc_tick_affine<2>, grid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
-            case 3: hipLaunchKernelGGL(ismpc_tick_affine<3>, grid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
-            case 4: hipLaunchKernelGGL(ismpc_tick_affine<4>, grid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame); break;
+            case 1: ISMPC_AFF(1); break;
+            case 2: ISMPC_AFF(2); break;
+            case 3: ISMPC_AFF(3); break;
+            case 4: ISMPC_AFF(4); break;
             default: return fail(ISMPC_E_UNSUPPORTED, "horizon N > 256");
         }
+#undef ISMPC_AFF
         HIP_TRY(hipGetLastError());
         return ISMPC_OK;
     }
@@ -887,6 +1122,7 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
         if (v == 4 || v == 8 || v == 16) h->force_waves = v;
     }
     if (const char* pth = std::getenv("ISMPC_PATH")) h->dense_path = std::strcmp(pth, "dense") == 0;
+    if (const char* zf = std::getenv("ISMPC_Z_FALLBACK")) h->z_fallback = std::atoi(zf) != 0;   // 0: flag only, no second launch
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete h; return fail(ISMPC_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
     const ismpc::Tables& t = h->t;
@@ -914,6 +1150,9 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     if (rc == ISMPC_OK) rc = upload(h, t.SdU, &c.SdU);
     if (rc == ISMPC_OK) rc = upload(h, t.Wt, &c.Wt);
     if (rc == ISMPC_OK) rc = upload(h, t.SW, &c.SW);
+    if (rc == ISMPC_OK) rc = upload(h, t.HSt, &c.HSt);
+    if (rc == ISMPC_OK) rc = upload(h, t.SHSt, &c.SHSt);
+    if (rc == ISMPC_OK) { std::vector<int> zf(1, 0); const int* zp = nullptr; rc = upload(h, zf, &zp); c.zflag = const_cast<int*>(zp); }
     c.flat = t.flat ? 1 : 0;
     if (rc != ISMPC_OK) { ismpc_destroy(h); return rc; }
     if (hipStreamCreate(&h->own_stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
@@ -929,6 +1168,7 @@ void ismpc_destroy(ismpc_handle* h)
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->st_in) (void)hipFree(h->st_in);
     if (h->st_out) (void)hipFree(h->st_out);
+    if (h->zmark) (void)hipFree(h->zmark);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

@@ -214,15 +214,28 @@ int build_tables(const ismpc_params& p, const double* ftsp, int rows, Tables& t,
             apply_Hinv(g, du); apply_S(du, sdu);
             for (int n = 0; n < N; ++n) { t.dU[(size_t)idx*NT + n] = (double)du[n]; t.SdU[(size_t)idx*NT + n] = (double)sdu[n]; }
         }
+    }
+    // equality corrections re-strided to NT (non-flat plans and the inequality fallback both use them)
+    {
         t.Wt.assign((size_t)t.npat * t.Fmax * NT, 0.0); t.SW.assign((size_t)t.npat * t.Fmax * NT, 0.0);
         std::vector<ld> col(N), scol;
         for (int it = 0; it < t.npat; ++it)
             for (int e = 0; e < t.ne[it]; ++e) {
                 for (int n = 0; n < N; ++n) col[n] = Wld[((size_t)it*t.Fmax + e)*N + n];
-                // on the equality samples the corrected u is forced to 0 by the kernel; elsewhere W applies
                 apply_S(col, scol);
                 for (int n = 0; n < N; ++n) { t.Wt[((size_t)it*t.Fmax + e)*NT + n] = (double)col[n]; t.SW[((size_t)it*t.Fmax + e)*NT + n] = (double)scol[n]; }
             }
+    }
+    // ---- inequality fallback (0 <= S u <= 1e4 active, MPCSolver.cpp:158-160): for row k of S_bar_z,
+    // hs_k = Hinv S_k' and shs_k = S hs_k; the equality pattern is folded in at run time with W / SW.
+    {
+        t.HSt.assign((size_t)N * NT, 0.0); t.SHSt.assign((size_t)N * NT, 0.0);
+        std::vector<ld> srow(N), hs, shs;
+        for (int k = 0; k < N; ++k) {
+            for (int j = 0; j < N; ++j) srow[j] = j < k ? cs * (ld)(k - j) : 0;      // S_bar_z(k, j)
+            apply_Hinv(srow, hs); apply_S(hs, shs);
+            for (int n = 0; n < N; ++n) { t.HSt[(size_t)k*NT + n] = (double)hs[n]; t.SHSt[(size_t)k*NT + n] = (double)shs[n]; }
+        }
     }
     return ISMPC_OK;
 }

@@ -39,8 +39,10 @@ struct Tables {
     std::vector<double> tz, tg;             // NT each: T_bar_z(n,1) = (n+1) dt ; T_bar_g_z(n) = -g dt^2 n(n+1)/2
     bool flat = true;                       // ftsp_midpoint(:,2) == 0 everywhere (the reference's plan, Controller.cpp:95)
     std::vector<double> dU, SdU;            // nmid x NT each (only when !flat): Hinv q_p S' mid_z[idx:idx+N] and S_z times it
-    std::vector<double> SW;                 // npat x Fmax x NT (only when !flat): S_z W_p
-    std::vector<double> Wt;                 // npat x Fmax x NT (only when !flat): W_p re-strided to NT
+    std::vector<double> SW;                 // npat x Fmax x NT: S_z W_p
+    std::vector<double> Wt;                 // npat x Fmax x NT: W_p re-strided to NT
+    // inequality fallback (0 <= S u <= 1e4 active): row k holds Hinv S_k' / S Hinv S_k'
+    std::vector<double> HSt, SHSt;          // N x NT each
 };
 
 // Returns ISMPC_OK or an ISMPC_E_* code; on error `err` explains.
