@@ -34,6 +34,19 @@ def algorithmic_flops_per_tick(N):
     return 6.0 * N * N + 20.0 * N
 
 
+def measured_traffic(N, B):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_affine_b8192.json:
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads, + WRITE_SIZE), scaled by
+    instances per launch; None when no profile of this kernel/horizon is committed."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_affine_b8192.json")
+    if not os.path.exists(path) or os.environ.get("ISMPC_PATH") == "dense":
+        return None
+    j = json.load(open(path))
+    if j.get("horizon") != N:
+        return None
+    return j["derived"]["hbm_bytes_per_launch"] * B / j["batch"]
+
+
 def cpu_baseline(N, tick_in, budget_s=20.0):
     """The reference's single-thread qpOASES path on this box's host cores: the CPU restatement of
     MPCSolver::solve with every QP solved by the reference's own vendored qpOASES (oracle/_ref),
@@ -162,11 +175,13 @@ def main():
                        "flight_fraction": frac_flight, "infeasible_fraction": frac_infeasible},
             "qp_solves_per_s": 3.0 * value,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": measured_traffic(N, B),
                          "kernel": ("ismpc_tick_dense<%d,16>" if os.environ.get("ISMPC_PATH") == "dense" else "ismpc_tick_affine<%d>") % ((N + 63) // 64), "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_launch": flops,
                          "note": "FP64 compute roofline (vector = matrix peak 78.6 TF); algorithmic flops 6N^2+20N per tick, "
-                                 "shared vertical factor; algorithmic HBM bytes 152 B/tick are ~1e-4 of the HBM roofline"},
+                                 "shared vertical factor; algorithmic HBM bytes 152 B/tick are ~1e-4 of the HBM roofline; "
+                                 "traffic = HBM bytes/launch from rocprofv3 PMC (profiles/r01/pmc_affine_b8192.json), "
+                                 "measured at 8192 instances/launch and scaled linearly to this batch"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, tick_in, args.cpu_budget)

@@ -42,6 +42,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 struct DevConst {
     int N, NP, NPs, S, F, nmid, npat, Fmax, rows, tick_divisor;
     double dt, cdt, mass, g, h_des, half_run, half_first, q_p, q_u, q_v, z_lo, z_hi, gate, eta;
+    double inv_mass, dt_over_mass, inv_eta, sim_div, cdt_over_dt;   // 1/m, dt/m (B_z), 1/eta (C_sc), dt/cdt, cdt/dt: uniform divisions hoisted to the host
     const double *Hinv, *W, *midx, *midy, *midz, *tailx, *taily, *ftsp_t;
     const int *e_lo, *ne;
     // affine form of the vertical stage (ismpc_tables.hpp)
@@ -167,7 +168,7 @@ __device__ __forceinline__ int gate_tick(const DevConst& c, const Walk& w, int& 
 {
     idx = 0;
     if ((w.ctl % c.tick_divisor) != 0) return ISMPC_ST_TICK_SKIPPED;
-    const double t = w.sim / (c.dt / c.cdt);
+    const double t = (c.sim_div == 1.0) ? w.sim : w.sim / c.sim_div;
     if (!(t > -1.0) || !(t < 2.0e9)) return ISMPC_ST_BAD_INDEX;
     idx = (int)t;
     if (idx < 0 || idx + 2 * c.N > c.nmid || w.mpc < 0) return ISMPC_ST_BAD_INDEX;
@@ -745,13 +746,6 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
 #pragma unroll
         for (int r = 0; r < R; ++r) su[r] = fma(zd0, t2[r], fma(z0, t1[r], t0[r]));
         loadR<R>(c.tz + n0, tz); loadR<R>(c.tg + n0, tg);
-        double mx[R], my[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {                  // issued early: used after the scan
-            const int n = n0 + r;
-            mx[r] = (n < N) ? c.midx[idx + n] : 0.0; my[r] = (n < N) ? c.midy[idx + n] : 0.0;
-        }
-        const double tailx = c.tailx[idx], taily = c.taily[idx];
         if (!c.flat) {                                  // plans with mid_z != 0 (MPCSolver.cpp:259)
             double du[R], ds[R];
             loadR<R>(c.dU + (size_t)idx * NT + n0, du); loadR<R>(c.SdU + (size_t)idx * NT + n0, ds);
@@ -788,12 +782,12 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double zpos = su[r] + fma(tz[r], zd0, z0) + tg[r];            // S u + T_bar_z s + T_bar_g_z
-            const double zacc = (1.0 / c.mass) * u[r] - c.g;
+            const double zacc = c.inv_mass * u[r] - c.g;
             lam[r] = (c.g + zacc) / zpos;                                       // MPCSolver.cpp:306
         }
         uz0 = bcast0(u[0]);
         o_z = z0 + dt * zd0;                                                    // MPCSolver.cpp:274-278
-        o_zd = zd0 + (dt / c.mass) * uz0 - dt * c.g;
+        o_zd = zd0 + c.dt_over_mass * uz0 - dt * c.g;
         if (isnan(o_z)) { o_z = c.h_des; status |= ISMPC_ST_Z_NAN; }
         if (isnan(o_zd)) { o_zd = 0.0; status |= ISMPC_ST_Z_NAN; }
 
@@ -838,7 +832,7 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
             for (int r = 1; r < R; ++r) Y = mul((M2){1.0 + ch1[r], s1[r], s2[r], 1.0 + ch1[r]}, Y);
             scan_step<0x101>(Y); scan_step<0x102>(Y); scan_step<0x104>(Y); scan_step<0x108>(Y);   // row_shl 1,2,4,8
             // g_row = C_sc P_3 .. P_{row+1}  (P_r = product of row r = Y at its first lane), C_sc = [1, 1/eta]
-            const double ie = 1.0 / c.eta;
+            const double ie = c.inv_eta;
             const M2 p1 = readlane_m2<16>(Y), p2 = readlane_m2<32>(Y), p3 = readlane_m2<48>(Y);
             const double g2a = fma(ie, p3.c, p3.a), g2b = fma(ie, p3.d, p3.b);
             const double g1a = fma(g2b, p2.c, g2a * p2.a), g1b = fma(g2b, p2.d, g2a * p2.b);
@@ -860,6 +854,13 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
             const double h = (w.fc > 1) ? c.half_run : c.half_first;            // MPCSolver.cpp:328-338
             hbox = h;
             double q0 = 0.0, s_ax = 0.0, s_ay = 0.0;
+            double mx[R], my[R];                          // loaded here, not earlier: 8 waves per SIMD hide the latency, registers are the scarce resource
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int n = n0 + r;
+                mx[r] = (n < N) ? c.midx[idx + n] : 0.0; my[r] = (n < N) ? c.midy[idx + n] : 0.0;
+            }
+            const double tailx = c.tailx[idx], taily = c.taily[idx];
 #pragma unroll
             for (int r = 0; r < R; ++r) { q0 = fma(a[r], a[r], q0); s_ax = fma(a[r], mx[r], s_ax); s_ay = fma(a[r], my[r], s_ay); }
             q0 = wave_sum(q0); s_ax = wave_sum(s_ax); s_ay = wave_sum(s_ay);
@@ -869,7 +870,8 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
             // min 1/2|v|^2, a'v = bp, |v| <= h  ->  v_n = sg sign(a_n) min(tau |a_n|, h): Newton on the concave
             // piecewise-linear G(tau) = sum |a_n| min(tau |a_n|, h) from tau = 0 (first step: tau = |bp| / sum a^2)
             const double T[2] = { fabs(bpx), fabs(bpy) };
-            double tau[2] = { T[0] / q0, T[1] / q0 };
+            const double iq0 = 1.0 / q0;
+            double tau[2] = { T[0] * iq0, T[1] * iq0 };
             int its[2] = {1, 1};
             double aa[R];
 #pragma unroll
@@ -959,14 +961,16 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
         st->simulation_time = w.sim;
         const int ctl = w.ctl + 1;
         st->control_iter = ctl;
-        st->mpc_iter = (int)floor(ctl * c.cdt / c.dt);
+        st->mpc_iter = (int)floor(ctl * c.cdt / c.dt);     // as written at Controller.cpp:504: 29*0.01/0.01 floors to 28, and parity keeps that
         st->footstep_counter = w.fc;
     }
 }
 
 
+// 8 workgroups (one wavefront per SIMD each) must be co-resident per CU: <= 64 VGPRs and -- the binding one on
+// gfx950 -- <= 80 SGPRs (MI355X_MICROARCH.md "Residency": floor(800 / (ceil(sgpr/16)*16 + 16)) blocks per CU)
 template <int R>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
 void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                        ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
                        unsigned char* zmark, int launch_id)
@@ -1133,6 +1137,8 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     c.half_run = t.p.foot_width / 2; c.half_first = t.p.first_step_halfwidth;
     c.q_p = t.p.q_p; c.q_u = t.p.q_u; c.q_v = t.p.q_v; c.z_lo = t.p.z_ineq_lo; c.z_hi = t.p.z_ineq_hi;
     c.gate = t.p.lambda_gate; c.eta = t.eta;
+    c.inv_mass = 1.0 / t.p.mass; c.dt_over_mass = t.p.mpc_dt / t.p.mass; c.inv_eta = 1.0 / t.eta;
+    c.sim_div = t.p.mpc_dt / t.p.control_dt; c.cdt_over_dt = t.p.control_dt / t.p.mpc_dt;
     rc = upload(h, t.Hinv, &c.Hinv);
     if (rc == ISMPC_OK) rc = upload(h, t.W, &c.W);
     if (rc == ISMPC_OK) rc = upload(h, t.midx, &c.midx);
