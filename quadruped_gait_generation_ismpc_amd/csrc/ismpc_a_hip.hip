@@ -525,6 +525,500 @@ void ismpc_a_tick_kernel(const DevA c, const ismpc_a_state* __restrict__ state_i
     }
 }
 
+// =====================================================================================================
+// Wavefront-per-QP kernel: the STRUCTURED dual active-set solver (scripts/proto_structured.py is its numpy model).
+//
+// No matrix over the working set exists.  For the active ZMP rows, sorted by sample index i_1 < i_2 < ..., the
+// Gram block in the H^-1 metric is dt^2 min(i_j, i_k) + (footstep coupling)/Qf.  dt^2 min(.,.) is the covariance of
+// a random walk, so its inverse is TRIDIAGONAL: (K^-1 y)_j = (y_j - y_prev)/g_j - (y_next - y_j)/g_next with g the
+// index gaps -- each active row only needs its previous / next active row -- and K^-1 applied to a kernel column
+// min(i+, .) is linear interpolation at i+ (two non-zeros).  Everything else -- the footstep coupling M~ (F columns),
+// the stability row and the F kinematic rows -- is a rank <= 2F+1 border: V_i = [M~_i, dt PA_i, Bk_i] has a closed
+// form per row, G = V' K^-1 V / dt^2 (m x m, m = 2F+1) is kept by +/- one outer product per gap created/destroyed,
+// and one quasi-definite m x m system per step gives the border unknowns.  Step lengths, add / drop logic and
+// termination are Goldfarb-Idnani's.  Lanes own RL consecutive rows (row = ZMP sample), so the primal direction is
+// "own multiplier as an impulse + one suffix scan" with no scatter; wave collectives are DPP scans / min / max.
+// =====================================================================================================
+constexpr int MAXM = 2 * MAXF + 1;
+// Per-wavefront LDS.  Small vectors (length m = 2F+1 <= 17 or F+2) are kept ONE ELEMENT PER LANE in registers and
+// mirrored here when other lanes need them by index; nothing of size "working set" is stored anywhere.
+struct WaveLds {
+    double sv[T];                      // V_row . y of every ZMP row
+    double comb[MAXF + 2];             // footstep-column coefficients seen by a row: comb[k1], comb[k1+1]
+    double fl[MAXF + 2];               // f[0..F+1] with fl[0] = fl[F+1] = 0
+    double G[MAXM * MAXM];             // V' K^-1 V / dt^2 over the active ZMP rows
+    double K[MAXM * (MAXM + 1)];       // the small system, eliminated in place
+    double vp[MAXM], hx[MAXM], d1[MAXM], d2[MAXM], d0[MAXM], cc[MAXM], mt[MAXM];
+};
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+template <int CTRL, int RM> __device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xf, false); }
+__device__ __forceinline__ int wave_max_i(int v)
+{
+    const int lo = -2147483647 - 1;
+    v = max(v, dpp_i<0x111, 0xf>(lo, v)); v = max(v, dpp_i<0x112, 0xf>(lo, v)); v = max(v, dpp_i<0x114, 0xf>(lo, v));
+    v = max(v, dpp_i<0x118, 0xf>(lo, v)); v = max(v, dpp_i<0x142, 0xa>(lo, v)); v = max(v, dpp_i<0x143, 0xc>(lo, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min_i(int v) { return -wave_max_i(-v); }
+__device__ __forceinline__ double wave_min_d(double v)
+{
+    v = fmin(v, dpp64<0x111, 0xf, false>(INFINITY, v)); v = fmin(v, dpp64<0x112, 0xf, false>(INFINITY, v));
+    v = fmin(v, dpp64<0x114, 0xf, false>(INFINITY, v)); v = fmin(v, dpp64<0x118, 0xf, false>(INFINITY, v));
+    v = fmin(v, dpp64<0x142, 0xa, false>(INFINITY, v)); v = fmin(v, dpp64<0x143, 0xc, false>(INFINITY, v));
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    v = wave_scan_up(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ double rl_d(double v, int l)
+{
+    const int ll = __builtin_amdgcn_readfirstlane(l);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), ll), __builtin_amdgcn_readlane(__double2loint(v), ll));
+}
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+
+// value held by the owner of ZMP row `row` (1-based, wave-uniform) in a per-row register array
+template <int RL> __device__ __forceinline__ double at_row(const double (&v)[RL], int row)
+{
+    const int o = (row - 1) / RL, k = (row - 1) - o * RL;
+    double x = v[0];
+#pragma unroll
+    for (int r = 1; r < RL; ++r) if (k == r) x = v[r];
+    return rl_d(x, o);
+}
+template <int RL> __device__ __forceinline__ int at_row(const int (&v)[RL], int row)
+{
+    const int o = (row - 1) / RL, k = (row - 1) - o * RL;
+    int x = v[0];
+#pragma unroll
+    for (int r = 1; r < RL; ++r) if (k == r) x = v[r];
+    return rl_i(x, o);
+}
+// element `e` (this lane's) of the border row V = [M~ (F), dt PA, Bk (F)] of a ZMP row with mapping (k1, w1, w2), PA = pa
+__device__ __forceinline__ double border_elem(int e, int F, int k1, double w1, double w2, double pa, double dt, double isq)
+{
+    if (e == F) return dt * pa;
+    const int r = e < F ? e + 1 : e - F;                  // footstep column 1..F
+    const double mr = (r == k1) ? w1 : ((r == k1 + 1) ? w2 : 0.0);
+    if (e < F) return mr * isq;
+    const double mp = (r - 1 >= 1) ? ((r - 1 == k1) ? w1 : ((r - 1 == k1 + 1) ? w2 : 0.0)) : 0.0;
+    return (-mr + mp) * isq;
+}
+// G += sgn * [ c1 d1 d1' + c2 d2 d2' - c0 d0 d0' ]   (a gap of the sorted active set splits / two gaps merge)
+__device__ __forceinline__ void gram_update(WaveLds& L, int lane, int m, double sgn, double c1, double c2, double c0)
+{
+    for (int e = lane; e < m * m; e += 64) {
+        const int i = e / m, jj = e - i * m;
+        L.G[e] += sgn * (c1 * L.d1[i] * L.d1[jj] + c2 * L.d2[i] * L.d2[jj] - c0 * L.d0[i] * L.d0[jj]);
+    }
+}
+
+template <int RL>
+__global__ __launch_bounds__(T)
+void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
+                       const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch)
+{
+    __shared__ WaveLds lds_all[T / 64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveLds& L = lds_all[wv];
+    const int C = c.C, P = c.P, F = c.F, m = 2 * c.F + 1;
+    const double dt = c.dt, Qf = c.Qf, sq = sqrt(c.Qf), isq = 1.0 / sq, idt2 = 1.0 / (dt * dt);
+    const bool klane = lane >= 1 && lane <= F;            // lane r owns kinematic row r (and f_r)
+
+    for (int work = blockIdx.x * (T / 64) + wv; work < 2 * batch; work += gridDim.x * (T / 64)) {
+        const int inst = work >> 1, axis = work & 1;
+        const ismpc_a_state st = state_in[inst];
+        const double pos = axis == 0 ? st.x : st.y;
+        const double vel = (axis == 0 ? st.xd : st.yd) + (push ? push[inst * 2 + axis] : 0.0);
+        const double zmp = axis == 0 ? st.xz : st.yz;
+        const double cur = axis == 0 ? st.cur_x : st.cur_y;
+        const double off = axis == 0 ? st.off_x : st.off_y;
+        const int j = st.j, fc = st.fc;
+        const double* fs = axis == 0 ? c.fsx : c.fsy;
+        const double* cl = st.rebuilt ? (axis == 0 ? c.clx1 : c.cly1) : (axis == 0 ? c.clx0 : c.cly0);
+        const double cloff = st.rebuilt ? off : 0.0;
+        int status = 0;
+        if (fc < 1 || fc + F > c.n_gait || j < 1 || j + P > c.ncl || j < c.step * (fc - 1) || j > c.step * fc - 1)
+            status |= ISMPC_A_ST_BAD_INDEX;
+
+        // ---- per-row data: lane owns ZMP rows lane*RL+1 .. lane*RL+RL (row i = sample i, u index i-1)
+        double u[RL], av[RL], pa[RL], zlo[RL], zhi[RL], w1[RL], w2[RL], inrm[RL], mu[RL];
+        int k1[RL], sta[RL], prv[RL], nxt[RL];
+        bool ovf = false;
+#pragma unroll
+        for (int k = 0; k < RL; ++k) {
+            const int i = lane * RL + k + 1;
+            u[k] = 0.0; mu[k] = 0.0; sta[k] = 0; prv[k] = 0; nxt[k] = 0;
+            if (i <= C) {
+                int pf = (j + i) / c.step - fc + 1; if (pf < 0) pf = 0;
+                const int rem = c.step * (fc + pf) - (j + i);
+                if (rem > c.ds) { w1[k] = 1.0; w2[k] = 0.0; } else { w1[k] = (double)rem / c.ds; w2[k] = 1.0 - (double)rem / c.ds; }
+                k1[k] = pf;
+                ovf = ovf || pf > F || (rem <= c.ds && pf + 1 > F);
+                const double m1 = (pf == 0) ? w1[k] : 0.0;
+                zhi[k] = 1.0 * (-zmp + c.w / 2) + m1 * cur;
+                zlo[k] = -(-1.0 * (-zmp - c.w / 2) - m1 * cur);
+                av[k] = c.a[i - 1]; pa[k] = c.PA[i];
+                double mm = w2[k] * w2[k];                             // |M_i|^2 over the footstep columns
+                if (pf >= 1) mm += w1[k] * w1[k];
+                inrm[k] = 1.0 / sqrt(dt * dt * (double)i + mm / Qf);
+            } else { w1[k] = 0.0; w2[k] = 0.0; k1[k] = 0; zlo[k] = -INFINITY; zhi[k] = INFINITY; av[k] = 0.0; pa[k] = 0.0; inrm[k] = 0.0; }
+        }
+        if (__builtin_amdgcn_ballot_w64(ovf) != 0) status |= ISMPC_A_ST_OVERFLOW;
+        // anticipative tail (quad_walk_no_plots.m:227-231)
+        double tl = 0.0;
+        if (!(status & ISMPC_A_ST_BAD_INDEX))
+            for (int i = C + 1 + lane; i <= P; i += 64) tl += c.wtail[i - (C + 1)] * ((cl[j + i - 1] + cloff) - cur);
+        double tail = wave_sum_d(tl);
+        if (!(status & ISMPC_A_ST_BAD_INDEX)) tail += c.wP * ((cl[P - 1] + cloff) - cur);
+        const double beq = pos + vel / c.eta - zmp - tail;
+        // ---- kinematic row r and footstep f_r live in lane r (1..F); Khat_r = sqrt(Qf) (f_r - f_{r-1})
+        double fr = 0.0, klo = -INFINITY, khi = INFINITY, muK = 0.0;
+        int kact = 0;
+        if (klane) {
+            const int r = lane;
+            double bup = axis == 0 ? c.disp_forw : (c.disp_L / 2 + c.disp_L / 2);
+            if (fc == 1 && r == 1) bup = axis == 0 ? c.disp_forw_dummy : (c.disp_L / 2 + c.disp_L / 2);
+            double blo = bup;
+            if (r == 1) { bup = bup + cur; blo = blo - cur; }
+            khi = bup; klo = -blo;
+            fr = (status & ISMPC_A_ST_BAD_INDEX) ? 0.0 : fs[fc + r - 1] + off;
+        }
+        const double knrm = (lane >= 2) ? sq * 0.70710678118654752440 : sq;   // 1 / |K_r|_{H^-1}: |kvec_r|^2 = 2 (r >= 2) or 1
+        int iters = 0, qz = 0, qk = 0;
+        double muE = 0.0;
+        if (status == 0) {
+            // ---- equality first: u = (b / a'a) a
+            const double t0 = beq / c.aa;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) u[k] = t0 * av[k];
+            muE = t0;
+            for (int e = lane; e < m * m; e += 64) L.G[e] = 0.0;
+            WAVE_LDS_SYNC();
+
+            for (;;) {
+                // ================= most violated inactive row =================
+                if (lane <= F + 1) L.fl[lane] = fr;
+                WAVE_LDS_SYNC();
+                double cand = 0.0; int code = 0;
+                {
+                    double loc = 0.0, cum[RL];
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) { loc += u[k]; cum[k] = loc; }
+                    const double base = wave_scan_up(loc) - loc;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        if (i <= C && sta[k] == 0) {
+                            const double v = dt * (cum[k] + base) - (w1[k] * L.fl[k1[k]] + w2[k] * L.fl[k1[k] + 1]);
+                            const double vl = v - zlo[k], vh = zhi[k] - v;
+                            const double tol = 1e-11 * (fabs(v) + fmax(fabs(zlo[k]), fabs(zhi[k]))) + 1e-13;
+                            if (vl < -tol && vl * inrm[k] < cand) { cand = vl * inrm[k]; code = 2 * i; }
+                            if (vh < -tol && vh * inrm[k] < cand) { cand = vh * inrm[k]; code = 2 * i + 1; }
+                        }
+                    }
+                    const double fprev = dpp64<0x111, 0xf, true>(0.0, fr);        // f_{r-1} (lane 0 holds f_0 = 0)
+                    if (klane && kact == 0) {
+                        const double v = fr - fprev;
+                        const double vl = v - klo, vh = khi - v;
+                        const double tol = 1e-11 * (fabs(v) + fmax(fabs(klo), fabs(khi))) + 1e-13;
+                        if (vl < -tol && vl * knrm < cand) { cand = vl * knrm; code = 2 * (C + lane); }
+                        if (vh < -tol && vh * knrm < cand) { cand = vh * knrm; code = 2 * (C + lane) + 1; }
+                    }
+                }
+                const double vmin = wave_min_d(cand);
+                if (!(vmin < 0.0)) break;                                         // feasible: done
+                const int cd = rl_i(code, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(cand == vmin)));
+                const int row = cd >> 1;
+                const double sg = (cd & 1) ? -1.0 : 1.0;
+                const bool isZ = row <= C;
+                const int kr = row - C;                                           // kinematic index when !isZ
+                // ---- the new row: border row Vp (one element per lane), footstep part mt, norm, border products dX
+                int p_k1 = 0; double p_w1 = 0.0, p_w2 = 0.0, p_pa = 0.0;
+                if (isZ) { p_k1 = at_row<RL>(k1, row); p_w1 = at_row<RL>(w1, row); p_w2 = at_row<RL>(w2, row); p_pa = at_row<RL>(pa, row); }
+                const double vp = (isZ && lane < m) ? border_elem(lane, F, p_k1, p_w1, p_w2, p_pa, dt, isq) : 0.0;
+                double mt_e = 0.0, dx_e = 0.0;                                    // lane e: mt[e] (e < F), dX[e] (e >= F)
+                if (isZ) { if (lane < F) mt_e = sg * vp; else if (lane < m) dx_e = sg * vp; }
+                else {
+                    if (lane < F) { const int r = lane + 1; mt_e = (r == kr) ? -sg : ((r == kr - 1) ? sg : 0.0); }      // -sg kvec
+                    else if (lane > F && lane < m) { const int r = lane - F; dx_e = sg * ((r == kr) ? (kr >= 2 ? 2.0 : 1.0) : ((r == kr - 1 || r == kr + 1) ? -1.0 : 0.0)); }
+                }
+                if (lane < m) { L.vp[lane] = vp; L.mt[lane] = mt_e; }
+                const double npn = isZ ? (dt * dt * (double)row + ((p_k1 >= 1 ? p_w1 * p_w1 : 0.0) + p_w2 * p_w2) / Qf) : (kr >= 2 ? 2.0 : 1.0);
+                double mu_p = 0.0;
+                bool failed = false;
+                // ================= steps until the row enters (Goldfarb-Idnani) =================
+                for (;;) {
+                    if (++iters > c.max_iter) { status |= ISMPC_A_ST_ITER_LIMIT; failed = true; break; }
+                    // ---- violation of the row at the current point
+                    double sviol;
+                    if (lane <= F + 1) L.fl[lane] = fr;
+                    WAVE_LDS_SYNC();
+                    if (isZ) {
+                        double lc = 0.0, cm[RL], vv[RL];
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) { lc += u[k]; cm[k] = lc; }
+                        const double bs = wave_scan_up(lc) - lc;
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) vv[k] = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + w2[k] * L.fl[k1[k] + 1]);
+                        const double v = at_row<RL>(vv, row);
+                        sviol = sg > 0.0 ? v - at_row<RL>(zlo, row) : at_row<RL>(zhi, row) - v;
+                    } else {
+                        const double fprev = dpp64<0x111, 0xf, true>(0.0, fr);
+                        const double vk = sg > 0.0 ? (fr - fprev) - klo : khi - (fr - fprev);
+                        sviol = sq * rl_d(vk, kr);
+                    }
+                    // ---- neighbours (na < row < nb) of a new ZMP row among the active ones; V there
+                    int na = 0, nb = 0; double th = 0.0, va = 0.0, vb = 0.0, vint = 0.0;
+                    if (isZ && qz > 0) {
+                        int la = 0, lb = 1 << 30;
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            if (sta[k] != 0 && i < row) la = max(la, i);
+                            if (sta[k] != 0 && i > row) lb = min(lb, i);
+                        }
+                        na = wave_max_i(la); nb = wave_min_i(lb); if (nb == (1 << 30)) nb = 0;
+                        if (na > 0) { const int q1 = at_row<RL>(k1, na); const double q2 = at_row<RL>(w1, na), q3 = at_row<RL>(w2, na), q4 = at_row<RL>(pa, na);
+                                      if (lane < m) va = border_elem(lane, F, q1, q2, q3, q4, dt, isq); }
+                        if (nb > 0) { const int q1 = at_row<RL>(k1, nb); const double q2 = at_row<RL>(w1, nb), q3 = at_row<RL>(w2, nb), q4 = at_row<RL>(pa, nb);
+                                      if (lane < m) vb = border_elem(lane, F, q1, q2, q3, q4, dt, isq); }
+                        if (nb == 0) { vint = va; th = 0.0; }
+                        else if (na == 0) { th = (double)row / (double)nb; vint = th * vb; }
+                        else { th = (double)(row - na) / (double)(nb - na); vint = va + th * (vb - va); }
+                    }
+                    // ---- small quasi-definite system  [[I+G11, G1x],[Gx1, Gxx - Sxx]] cc = [h1 ; hx - dX]
+                    // unknown order: 0..F-1 footstep columns, F = stability row, F+1..2F = Khat_1..F (inactive: pinned to 0)
+                    double h_e = 0.0;                                            // lane e: h[e] - dX[e]
+                    if (lane < m) {
+                        h_e = sg * vint;
+                        for (int r = 0; r < F; ++r) h_e += L.G[lane * m + r] * L.mt[r];
+                        h_e -= dx_e;
+                        L.hx[lane] = h_e;
+                    }
+                    WAVE_LDS_SYNC();
+                    const unsigned long long kmask = __builtin_amdgcn_ballot_w64(klane && kact != 0);   // bit r: Khat_r active
+                    for (int e = lane; e < m * (m + 1); e += 64) {
+                        const int i = e / (m + 1), jj = e - i * (m + 1);
+                        const bool ipin = i > F && !((kmask >> (i - F)) & 1ull);
+                        const bool jpin = jj > F && jj < m && !((kmask >> (jj - F)) & 1ull);
+                        double val;
+                        if (jj < m) {
+                            val = L.G[i * m + jj];
+                            if (i < F && jj == i) val += 1.0;
+                            if (i == F && jj == F) val -= c.aa;
+                            if (i > F && jj > F) {
+                                const int r1 = i - F, r2 = jj - F;
+                                val -= (r1 == r2) ? (r1 >= 2 ? 2.0 : 1.0) : ((r1 - r2 == 1 || r2 - r1 == 1) ? -1.0 : 0.0);
+                            }
+                            if (ipin || jpin) val = (i == jj) ? -1.0 : 0.0;
+                        } else {
+                            val = ipin ? 0.0 : L.hx[i];
+                        }
+                        L.K[e] = val;
+                    }
+                    WAVE_LDS_SYNC();
+                    for (int kk = 0; kk < m; ++kk) {                              // Gauss-Jordan, no pivoting (quasi-definite)
+                        const double ipv = 1.0 / L.K[kk * (m + 1) + kk];
+                        double upd[(MAXM * (MAXM + 1) + 63) / 64];
+                        int cnt = 0;
+                        for (int e = lane; e < m * (m + 1); e += 64, ++cnt) {
+                            const int i = e / (m + 1), jj = e - i * (m + 1);
+                            upd[cnt] = (i != kk && jj > kk) ? L.K[e] - L.K[i * (m + 1) + kk] * L.K[kk * (m + 1) + jj] * ipv : L.K[e];
+                        }
+                        WAVE_LDS_SYNC();
+                        cnt = 0;
+                        for (int e = lane; e < m * (m + 1); e += 64, ++cnt) L.K[e] = upd[cnt];
+                        WAVE_LDS_SYNC();
+                    }
+                    const double cc_e = (lane < m) ? L.K[lane * (m + 1) + m] / L.K[lane * (m + 1) + lane] : 0.0;   // lane e: cc[e]
+                    if (lane < m) L.cc[lane] = cc_e;
+                    WAVE_LDS_SYNC();
+                    const double cE = L.cc[F];
+                    // ---- y = coefficients on the V columns (delta_Z - V cc = sg dt^2 k_i + V y); rows see the footstep
+                    // columns through comb[k1], comb[k1+1]:  comb[r] = (yM_r - yK_r + yK_{r+1}) / sqrt(Qf)
+                    if (lane <= F + 1) {
+                        double cb = 0.0;
+                        if (klane) {
+                            const int r = lane;
+                            const double yM = L.mt[r - 1] - L.cc[r - 1], yK = -L.cc[F + r], yKn = (r + 1 <= F) ? -L.cc[F + r + 1] : 0.0;
+                            cb = (yM - yK + yKn) * isq;
+                        }
+                        L.comb[lane] = cb;
+                    }
+                    WAVE_LDS_SYNC();
+                    double svl[RL];
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        svl[k] = (i <= C) ? (w1[k] * L.comb[k1[k]] + w2[k] * L.comb[k1[k] + 1]) - dt * pa[k] * cE : 0.0;
+                        if (i <= C) L.sv[i - 1] = svl[k];
+                    }
+                    WAVE_LDS_SYNC();
+                    // ---- rho per active ZMP row (tridiagonal K^-1) + interpolation weights; d.r ; dual step length
+                    double rho[RL], ddl = 0.0, tcand = INFINITY; int tcode = 0;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        rho[k] = 0.0;
+                        if (i <= C && sta[k] != 0) {
+                            const double sp = prv[k] > 0 ? L.sv[prv[k] - 1] : 0.0;
+                            double r_ = (svl[k] - sp) / (double)(i - prv[k]);
+                            if (nxt[k] > 0) r_ -= (L.sv[nxt[k] - 1] - svl[k]) / (double)(nxt[k] - i);
+                            r_ *= idt2;
+                            if (isZ) {
+                                if (i == na) r_ += (nb == 0) ? sg : sg * (1.0 - th);
+                                if (i == nb) r_ += sg * th;
+                            }
+                            rho[k] = r_;
+                            double dj;                                             // sg <row+, Z_i>
+                            if (isZ) {
+                                double mm = 0.0;                                   // M_p . M_i
+                                const int a1 = p_k1, b1 = k1[k];
+                                if (a1 >= 1) { if (a1 == b1) mm += p_w1 * w1[k]; else if (a1 == b1 + 1) mm += p_w1 * w2[k]; }
+                                { const int cx = a1 + 1; if (cx == b1 && b1 >= 1) mm += p_w2 * w1[k]; else if (cx == b1 + 1) mm += p_w2 * w2[k]; }
+                                dj = sg * (dt * dt * (double)min(row, i) + mm / Qf);
+                            } else {
+                                double mk = 0.0;                                   // M_i . kvec_kr
+                                if (k1[k] == kr) mk += w1[k];
+                                if (k1[k] + 1 == kr) mk += w2[k];
+                                if (kr - 1 >= 1) { if (k1[k] == kr - 1) mk -= w1[k]; if (k1[k] + 1 == kr - 1) mk -= w2[k]; }
+                                dj = sg * (-mk) * isq;
+                            }
+                            ddl += dj * r_;
+                            const double rs = (sta[k] > 0 ? 1.0 : -1.0) * r_;
+                            if (rs > 0.0) { const double tt = mu[k] / rs; if (tt < tcand) { tcand = tt; tcode = i; } }
+                        }
+                    }
+                    if (lane >= F && lane < m) ddl += dx_e * cc_e;                 // border part of d.r
+                    const double cK = (klane) ? L.cc[F + lane] : 0.0;              // lane r: unsigned cc of Khat_r
+                    if (klane && kact != 0) {
+                        const double rs = (kact > 0 ? 1.0 : -1.0) * cK;
+                        if (rs > 0.0) { const double tt = muK / rs; if (tt < tcand) { tcand = tt; tcode = C + lane; } }
+                    }
+                    const double gamma = npn - wave_sum_d(ddl);
+                    const double t1 = wave_min_d(tcand);
+                    int lrow = 0;
+                    if (t1 < INFINITY) lrow = rl_i(tcode, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(tcand == t1)));
+                    const double t2 = (gamma > 1e-12 * npn) ? -sviol / gamma : INFINITY;
+                    const double t = fmin(t1, t2);
+                    if (!(t < INFINITY)) { status |= (axis == 0 ? ISMPC_A_ST_X_INFEASIBLE : ISMPC_A_ST_Y_INFEASIBLE); failed = true; break; }
+                    // ---- primal step: z_u = suffix sum of (-dt rho, + sg dt at the new row) - r_E a ; z_f from cc
+                    if (t2 < INFINITY) {
+                        double ls = 0.0, suf[RL];
+#pragma unroll
+                        for (int k = RL - 1; k >= 0; --k) {
+                            const int i = lane * RL + k + 1;
+                            ls += -dt * rho[k] + ((isZ && i == row) ? sg * dt : 0.0);
+                            suf[k] = ls;                                          // inclusive suffix inside the lane
+                        }
+                        const double incl = wave_scan_up(ls);
+                        const double above = rl_d(incl, 63) - incl;               // lanes above this one
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) u[k] += t * ((suf[k] + above) - cE * av[k]);
+                        if (klane) {
+                            // z_f[r] = ( n+_f[r] + sqrt(Qf) c1[r] - sqrt(Qf) (cK[r] - cK[r+1]) ) / Qf
+                            const int r = lane;
+                            double nf = isZ ? -sg * L.vp[r - 1] * sq : ((r == kr) ? sg * sq : ((r == kr - 1) ? -sg * sq : 0.0));
+                            nf += sq * L.cc[r - 1];
+                            nf -= sq * cK;
+                            if (r + 1 <= F) nf += sq * L.cc[F + r + 1];
+                            fr += t * nf / Qf;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) if (sta[k] != 0) mu[k] -= t * (sta[k] > 0 ? 1.0 : -1.0) * rho[k];
+                    if (klane && kact != 0) muK -= t * (kact > 0 ? 1.0 : -1.0) * cK;
+                    muE -= t * cE;
+                    mu_p += t;
+                    if (t2 < INFINITY && t == t2) {
+                        // ============ the row enters ============
+                        if (isZ) {
+                            if (lane < m) { L.d1[lane] = vp - va; L.d2[lane] = (nb > 0 ? vb : 0.0) - vp; L.d0[lane] = (nb > 0 ? vb : 0.0) - va; }
+                            WAVE_LDS_SYNC();
+                            gram_update(L, lane, m, 1.0, idt2 / (double)(row - na), nb > 0 ? idt2 / (double)(nb - row) : 0.0,
+                                        nb > 0 ? idt2 / (double)(nb - na) : 0.0);
+                            WAVE_LDS_SYNC();
+#pragma unroll
+                            for (int k = 0; k < RL; ++k) {
+                                const int i = lane * RL + k + 1;
+                                if (i == row) { sta[k] = sg > 0.0 ? 1 : -1; mu[k] = mu_p; prv[k] = na; nxt[k] = nb; }
+                                if (i == na) nxt[k] = row;
+                                if (i == nb) prv[k] = row;
+                            }
+                            ++qz;
+                        } else {
+                            if (lane == kr) { kact = sg > 0.0 ? 1 : -1; muK = mu_p; }
+                            ++qk;
+                        }
+                        break;
+                    }
+                    // ============ partial step: working-set row lrow leaves ============
+                    if (lrow <= C) {
+                        const int pa_ = at_row<RL>(prv, lrow), pb_ = at_row<RL>(nxt, lrow);
+                        double vl_ = 0.0, wa_ = 0.0, wb_ = 0.0;
+                        { const int q1 = at_row<RL>(k1, lrow); const double q2 = at_row<RL>(w1, lrow), q3 = at_row<RL>(w2, lrow), q4 = at_row<RL>(pa, lrow);
+                          if (lane < m) vl_ = border_elem(lane, F, q1, q2, q3, q4, dt, isq); }
+                        if (pa_ > 0) { const int q1 = at_row<RL>(k1, pa_); const double q2 = at_row<RL>(w1, pa_), q3 = at_row<RL>(w2, pa_), q4 = at_row<RL>(pa, pa_);
+                                       if (lane < m) wa_ = border_elem(lane, F, q1, q2, q3, q4, dt, isq); }
+                        if (pb_ > 0) { const int q1 = at_row<RL>(k1, pb_); const double q2 = at_row<RL>(w1, pb_), q3 = at_row<RL>(w2, pb_), q4 = at_row<RL>(pa, pb_);
+                                       if (lane < m) wb_ = border_elem(lane, F, q1, q2, q3, q4, dt, isq); }
+                        if (lane < m) { L.d1[lane] = vl_ - wa_; L.d2[lane] = (pb_ > 0 ? wb_ : 0.0) - vl_; L.d0[lane] = (pb_ > 0 ? wb_ : 0.0) - wa_; }
+                        WAVE_LDS_SYNC();
+                        gram_update(L, lane, m, -1.0, idt2 / (double)(lrow - pa_), pb_ > 0 ? idt2 / (double)(pb_ - lrow) : 0.0,
+                                    pb_ > 0 ? idt2 / (double)(pb_ - pa_) : 0.0);
+                        WAVE_LDS_SYNC();
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            if (i == lrow) { sta[k] = 0; mu[k] = 0.0; prv[k] = 0; nxt[k] = 0; }
+                            if (i == pa_) nxt[k] = pb_;
+                            if (i == pb_) prv[k] = pa_;
+                        }
+                        --qz;
+                    } else {
+                        if (lane == lrow - C) { kact = 0; muK = 0.0; }
+                        --qk;
+                    }
+                }
+                if (failed) break;
+            }
+        }
+
+        // ---- LIP update (:297-322), footstep bookkeeping (:522-556), outputs
+        const bool ok = (status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) == 0;
+        const double u0 = ok ? rl_d(u[0], 0) : 0.0;
+        const double f0 = ok ? rl_d(fr, 1) : cur;
+        if (lane == 0) {
+            const double p0 = pos, v0 = vel, z0 = zmp;
+            const double np_ = (c.Au[0] * p0 + c.Au[1] * v0 + c.Au[2] * z0) + c.Bu[0] * u0;
+            const double nv_ = (c.Au[3] * p0 + c.Au[4] * v0 + c.Au[5] * z0) + c.Bu[1] * u0;
+            const double nz_ = (c.Au[6] * p0 + c.Au[7] * v0 + c.Au[8] * z0) + c.Bu[2] * u0;
+            ismpc_a_state* so = state + inst;
+            const bool stepped = ok && (j + 1 >= c.step * fc);
+            if (ok) {
+                if (axis == 0) { so->x = np_; so->xd = nv_; so->xz = nz_; } else { so->y = np_; so->yd = nv_; so->yz = nz_; }
+                if (stepped) {
+                    const double noff = f0 - fs[fc];
+                    if (axis == 0) { so->cur_x = f0; so->off_x = noff; } else { so->cur_y = f0; so->off_y = noff; }
+                }
+                if (axis == 0) { so->j = j + 1; if (stepped) { so->fc = fc + 1; so->rebuilt = 1; } }
+            }
+            if (out) {
+                ismpc_a_out* o = out + inst;
+                const int q = 1 + qz + qk;
+                o->com_before[axis] = pos; o->vel_after[axis] = ok ? nv_ : vel; o->u0[axis] = u0; o->f0[axis] = f0;
+                if (axis == 0) { o->iters_x = iters; atomicOr(&o->status, status); atomicOr(&o->active, q & 0xffff); }
+                else { o->iters_y = iters; atomicOr(&o->status, status); atomicOr(&o->active, (q & 0xffff) << 16); }
+            }
+        }
+    }
+}
+
 __global__ void ismpc_a_clear_out(ismpc_a_out* out, int batch)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -570,6 +1064,7 @@ struct ismpc_a_handle {
     DevA c{};
     int device = 0, slots = 0;
     ismpc_a_state* prev = nullptr; int prev_cap = 0;     // copy of the state the tick reads
+    bool use_wave = true; int wave_blocks = 0;           // structured wavefront-per-QP kernel (default) vs workgroup-per-QP
     std::vector<void*> allocs;
     std::vector<double> fsx, fsy;
 };
@@ -740,6 +1235,8 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) rc = fail_a(-2, "hipGetDeviceProperties failed");
         else {
             h->slots = prop.multiProcessorCount * (c.sinv_in_lds ? 1 : 4);   // persistent grid: workgroups per CU
+            h->wave_blocks = prop.multiProcessorCount * 4;
+            if (const char* e = std::getenv("ISMPC_A_KERNEL")) h->use_wave = std::strcmp(e, "block") != 0;
             void* sc = nullptr;
             if (hipMalloc(&sc, (size_t)h->slots * c.ldq * c.ldq * sizeof(double)) != hipSuccess) rc = fail_a(-3, "scratch allocation failed");
             else { h->allocs.push_back(sc); c.scratch = static_cast<double*>(sc); }
@@ -788,6 +1285,17 @@ int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state
     }
     HIP_TRY_A(hipMemcpyAsync(h->prev, state_dev, sizeof(ismpc_a_state) * (size_t)batch, hipMemcpyDeviceToDevice, s));
     if (out_dev) hipLaunchKernelGGL(ismpc_a_clear_out, dim3((batch + 255) / 256), dim3(256), 0, s, out_dev, batch);
+    if (h->use_wave) {
+        // structured solver, one wavefront per QP, 4 per workgroup; persistent grid
+        const int rl = (h->c.C + 63) / 64;
+        const int grid = std::min((2 * batch + 3) / 4, h->wave_blocks);
+        const ismpc_a_state* prev = h->prev;
+#define ISMPC_A_W(RL_) hipLaunchKernelGGL((ismpc_a_tick_wave<RL_>), dim3(grid), dim3(T), 0, s, h->c, prev, state_dev, push_dev, out_dev, batch)
+        bool launched = true;
+        switch (rl) { case 1: case 2: ISMPC_A_W(2); break; case 3: ISMPC_A_W(3); break; case 4: ISMPC_A_W(4); break; default: launched = false; }
+#undef ISMPC_A_W
+        if (launched) { HIP_TRY_A(hipGetLastError()); return 0; }
+    }
     const int grid = std::min(2 * batch, h->slots);
     hipLaunchKernelGGL(ismpc_a_tick_kernel, dim3(grid), dim3(T), h->c.sinv_in_lds ? (size_t)h->c.ldq * h->c.ldq * sizeof(double) : 0, s, h->c, (const ismpc_a_state*)h->prev, state_dev, push_dev, out_dev, batch);
     HIP_TRY_A(hipGetLastError());
