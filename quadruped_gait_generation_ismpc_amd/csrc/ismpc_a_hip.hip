@@ -540,15 +540,18 @@ void ismpc_a_tick_kernel(const DevA c, const ismpc_a_state* __restrict__ state_i
 // "own multiplier as an impulse + one suffix scan" with no scatter; wave collectives are DPP scans / min / max.
 // =====================================================================================================
 constexpr int MAXM = 2 * MAXF + 1;
-// Per-wavefront LDS.  Small vectors (length m = 2F+1 <= 17 or F+2) are kept ONE ELEMENT PER LANE in registers and
-// mirrored here when other lanes need them by index; nothing of size "working set" is stored anywhere.
-struct WaveLds {
+// Per-wavefront LDS.  Small vectors (length m = 2F+1 or F+2) are kept ONE ELEMENT PER LANE in registers and mirrored
+// here when other lanes need them by index; nothing of size "working set" is stored anywhere.
+template <int F> struct WaveLds {
+    static constexpr int m = 2 * F + 1;
     double sv[T];                      // V_row . y of every ZMP row
-    double comb[MAXF + 2];             // footstep-column coefficients seen by a row: comb[k1], comb[k1+1]
-    double fl[MAXF + 2];               // f[0..F+1] with fl[0] = fl[F+1] = 0
-    double G[MAXM * MAXM];             // V' K^-1 V / dt^2 over the active ZMP rows
-    double K[MAXM * (MAXM + 1)];       // the small system, eliminated in place
-    double vp[MAXM], hx[MAXM], d1[MAXM], d2[MAXM], d0[MAXM], cc[MAXM], mt[MAXM];
+    double w1s[T];                     // mapping weight of every row (wave-uniform look-ups by row index)
+    int    k1s[T];                     // first mapped footstep of every row
+    double comb[F + 2];                // footstep-column coefficients seen by a row: comb[k1], comb[k1+1]
+    double fl[F + 2];                  // f[0..F+1] with fl[0] = fl[F+1] = 0
+    double G[m * m];                   // V' K^-1 V / dt^2 over the active ZMP rows
+    double K[2][m * (m + 1)];          // the small system, Gauss-Jordan ping-pong
+    double vp[m], hx[m], d1[m], d2[m], d0[m], cc[m], mt[m];
 };
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
@@ -597,37 +600,35 @@ template <int RL> __device__ __forceinline__ int at_row(const int (&v)[RL], int 
     for (int r = 1; r < RL; ++r) if (k == r) x = v[r];
     return rl_i(x, o);
 }
-// element `e` (this lane's) of the border row V = [M~ (F), dt PA, Bk (F)] of a ZMP row with mapping (k1, w1, w2), PA = pa
-__device__ __forceinline__ double border_elem(int e, int F, int k1, double w1, double w2, double pa, double dt, double isq)
+// element `e` (this lane's) of the border row V = [M~ (F), dt PA, Bk (F)] of a ZMP row with mapping (k1, w1, 1-w1), PA = pa
+template <int F> __device__ __forceinline__ double border_elem(int e, int k1, double w1, double pa, double dt, double isq)
 {
     if (e == F) return dt * pa;
+    const double w2 = 1.0 - w1;
     const int r = e < F ? e + 1 : e - F;                  // footstep column 1..F
     const double mr = (r == k1) ? w1 : ((r == k1 + 1) ? w2 : 0.0);
     if (e < F) return mr * isq;
     const double mp = (r - 1 >= 1) ? ((r - 1 == k1) ? w1 : ((r - 1 == k1 + 1) ? w2 : 0.0)) : 0.0;
     return (-mr + mp) * isq;
 }
-// G += sgn * [ c1 d1 d1' + c2 d2 d2' - c0 d0 d0' ]   (a gap of the sorted active set splits / two gaps merge)
-__device__ __forceinline__ void gram_update(WaveLds& L, int lane, int m, double sgn, double c1, double c2, double c0)
-{
-    for (int e = lane; e < m * m; e += 64) {
-        const int i = e / m, jj = e - i * m;
-        L.G[e] += sgn * (c1 * L.d1[i] * L.d1[jj] + c2 * L.d2[i] * L.d2[jj] - c0 * L.d0[i] * L.d0[jj]);
-    }
-}
 
-template <int RL>
-__global__ __launch_bounds__(T)
+// RL = ZMP rows per lane (C <= 64 RL), F = footsteps in the horizon (m = 2F+1 border columns)
+template <int RL, int F>
+__global__ __launch_bounds__(T, 4)
 void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
                        const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch)
 {
-    __shared__ WaveLds lds_all[T / 64];
+    constexpr int m = 2 * F + 1, NK = m * (m + 1), NE = (NK + 63) / 64;
+    __shared__ WaveLds<F> lds_all[T / 64];
+    __shared__ double a_s[T], pa_s[T + 1];                  // stability row and its prefix sums: same for every QP of the handle
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveLds& L = lds_all[wv];
-    const int C = c.C, P = c.P, F = c.F, m = 2 * c.F + 1;
+    WaveLds<F>& L = lds_all[wv];
+    const int C = c.C, P = c.P;
     const double dt = c.dt, Qf = c.Qf, sq = sqrt(c.Qf), isq = 1.0 / sq, idt2 = 1.0 / (dt * dt);
     const bool klane = lane >= 1 && lane <= F;            // lane r owns kinematic row r (and f_r)
+    for (int k = threadIdx.x; k <= C; k += T) { pa_s[k] = c.PA[k]; if (k < C) a_s[k] = c.a[k]; }
+    __syncthreads();
 
     for (int work = blockIdx.x * (T / 64) + wv; work < 2 * batch; work += gridDim.x * (T / 64)) {
         const int inst = work >> 1, axis = work & 1;
@@ -644,9 +645,10 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
         int status = 0;
         if (fc < 1 || fc + F > c.n_gait || j < 1 || j + P > c.ncl || j < c.step * (fc - 1) || j > c.step * fc - 1)
             status |= ISMPC_A_ST_BAD_INDEX;
+        const double zlo0 = -(-1.0 * (-zmp - c.w / 2)), zhi0 = 1.0 * (-zmp + c.w / 2);       // band without the current-footstep term
 
         // ---- per-row data: lane owns ZMP rows lane*RL+1 .. lane*RL+RL (row i = sample i, u index i-1)
-        double u[RL], av[RL], pa[RL], zlo[RL], zhi[RL], w1[RL], w2[RL], inrm[RL], mu[RL];
+        double u[RL], zlo[RL], zhi[RL], w1[RL], inrm[RL], mu[RL];
         int k1[RL], sta[RL], prv[RL], nxt[RL];
         bool ovf = false;
 #pragma unroll
@@ -656,17 +658,17 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
             if (i <= C) {
                 int pf = (j + i) / c.step - fc + 1; if (pf < 0) pf = 0;
                 const int rem = c.step * (fc + pf) - (j + i);
-                if (rem > c.ds) { w1[k] = 1.0; w2[k] = 0.0; } else { w1[k] = (double)rem / c.ds; w2[k] = 1.0 - (double)rem / c.ds; }
+                w1[k] = (rem > c.ds) ? 1.0 : (double)rem / c.ds;                  // mapping(i, pf+1); the next column gets 1 - w1
                 k1[k] = pf;
                 ovf = ovf || pf > F || (rem <= c.ds && pf + 1 > F);
                 const double m1 = (pf == 0) ? w1[k] : 0.0;
-                zhi[k] = 1.0 * (-zmp + c.w / 2) + m1 * cur;
-                zlo[k] = -(-1.0 * (-zmp - c.w / 2) - m1 * cur);
-                av[k] = c.a[i - 1]; pa[k] = c.PA[i];
-                double mm = w2[k] * w2[k];                             // |M_i|^2 over the footstep columns
+                zhi[k] = zhi0 + m1 * cur; zlo[k] = zlo0 + m1 * cur;
+                const double w2 = 1.0 - w1[k];
+                double mm = w2 * w2;                                              // |M_i|^2 over the footstep columns
                 if (pf >= 1) mm += w1[k] * w1[k];
                 inrm[k] = 1.0 / sqrt(dt * dt * (double)i + mm / Qf);
-            } else { w1[k] = 0.0; w2[k] = 0.0; k1[k] = 0; zlo[k] = -INFINITY; zhi[k] = INFINITY; av[k] = 0.0; pa[k] = 0.0; inrm[k] = 0.0; }
+                L.k1s[i - 1] = pf; L.w1s[i - 1] = w1[k];
+            } else { w1[k] = 1.0; k1[k] = 0; zlo[k] = -INFINITY; zhi[k] = INFINITY; inrm[k] = 0.0; }
         }
         if (__builtin_amdgcn_ballot_w64(ovf) != 0) status |= ISMPC_A_ST_OVERFLOW;
         // anticipative tail (quad_walk_no_plots.m:227-231)
@@ -695,7 +697,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
             // ---- equality first: u = (b / a'a) a
             const double t0 = beq / c.aa;
 #pragma unroll
-            for (int k = 0; k < RL; ++k) u[k] = t0 * av[k];
+            for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; u[k] = (i <= C) ? t0 * a_s[i - 1] : 0.0; }
             muE = t0;
             for (int e = lane; e < m * m; e += 64) L.G[e] = 0.0;
             WAVE_LDS_SYNC();
@@ -704,7 +706,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 // ================= most violated inactive row =================
                 if (lane <= F + 1) L.fl[lane] = fr;
                 WAVE_LDS_SYNC();
-                double cand = 0.0; int code = 0;
+                double cand = 0.0, craw = 0.0; int code = 0;
                 {
                     double loc = 0.0, cum[RL];
 #pragma unroll
@@ -714,11 +716,11 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                     for (int k = 0; k < RL; ++k) {
                         const int i = lane * RL + k + 1;
                         if (i <= C && sta[k] == 0) {
-                            const double v = dt * (cum[k] + base) - (w1[k] * L.fl[k1[k]] + w2[k] * L.fl[k1[k] + 1]);
+                            const double v = dt * (cum[k] + base) - (w1[k] * L.fl[k1[k]] + (1.0 - w1[k]) * L.fl[k1[k] + 1]);
                             const double vl = v - zlo[k], vh = zhi[k] - v;
                             const double tol = 1e-11 * (fabs(v) + fmax(fabs(zlo[k]), fabs(zhi[k]))) + 1e-13;
-                            if (vl < -tol && vl * inrm[k] < cand) { cand = vl * inrm[k]; code = 2 * i; }
-                            if (vh < -tol && vh * inrm[k] < cand) { cand = vh * inrm[k]; code = 2 * i + 1; }
+                            if (vl < -tol && vl * inrm[k] < cand) { cand = vl * inrm[k]; craw = vl; code = 2 * i; }
+                            if (vh < -tol && vh * inrm[k] < cand) { cand = vh * inrm[k]; craw = vh; code = 2 * i + 1; }
                         }
                     }
                     const double fprev = dpp64<0x111, 0xf, true>(0.0, fr);        // f_{r-1} (lane 0 holds f_0 = 0)
@@ -726,21 +728,24 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         const double v = fr - fprev;
                         const double vl = v - klo, vh = khi - v;
                         const double tol = 1e-11 * (fabs(v) + fmax(fabs(klo), fabs(khi))) + 1e-13;
-                        if (vl < -tol && vl * knrm < cand) { cand = vl * knrm; code = 2 * (C + lane); }
-                        if (vh < -tol && vh * knrm < cand) { cand = vh * knrm; code = 2 * (C + lane) + 1; }
+                        if (vl < -tol && vl * knrm < cand) { cand = vl * knrm; craw = vl * sq; code = 2 * (C + lane); }
+                        if (vh < -tol && vh * knrm < cand) { cand = vh * knrm; craw = vh * sq; code = 2 * (C + lane) + 1; }
                     }
                 }
                 const double vmin = wave_min_d(cand);
                 if (!(vmin < 0.0)) break;                                         // feasible: done
-                const int cd = rl_i(code, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(cand == vmin)));
+                const int wl = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(cand == vmin));
+                const int cd = rl_i(code, wl);
+                double sviol = rl_d(craw, wl);
                 const int row = cd >> 1;
                 const double sg = (cd & 1) ? -1.0 : 1.0;
                 const bool isZ = row <= C;
                 const int kr = row - C;                                           // kinematic index when !isZ
                 // ---- the new row: border row Vp (one element per lane), footstep part mt, norm, border products dX
-                int p_k1 = 0; double p_w1 = 0.0, p_w2 = 0.0, p_pa = 0.0;
-                if (isZ) { p_k1 = at_row<RL>(k1, row); p_w1 = at_row<RL>(w1, row); p_w2 = at_row<RL>(w2, row); p_pa = at_row<RL>(pa, row); }
-                const double vp = (isZ && lane < m) ? border_elem(lane, F, p_k1, p_w1, p_w2, p_pa, dt, isq) : 0.0;
+                int p_k1 = 0; double p_w1 = 1.0, p_pa = 0.0;
+                if (isZ) { p_k1 = L.k1s[row - 1]; p_w1 = L.w1s[row - 1]; p_pa = pa_s[row]; }
+                const double p_w2 = 1.0 - p_w1;
+                const double vp = (isZ && lane < m) ? border_elem<F>(lane, p_k1, p_w1, p_pa, dt, isq) : 0.0;
                 double mt_e = 0.0, dx_e = 0.0;                                    // lane e: mt[e] (e < F), dX[e] (e >= F)
                 if (isZ) { if (lane < F) mt_e = sg * vp; else if (lane < m) dx_e = sg * vp; }
                 else {
@@ -750,28 +755,31 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 if (lane < m) { L.vp[lane] = vp; L.mt[lane] = mt_e; }
                 const double npn = isZ ? (dt * dt * (double)row + ((p_k1 >= 1 ? p_w1 * p_w1 : 0.0) + p_w2 * p_w2) / Qf) : (kr >= 2 ? 2.0 : 1.0);
                 double mu_p = 0.0;
-                bool failed = false;
+                bool failed = false, fresh = true;                                // fresh: sviol still valid from the search
                 // ================= steps until the row enters (Goldfarb-Idnani) =================
                 for (;;) {
                     if (++iters > c.max_iter) { status |= ISMPC_A_ST_ITER_LIMIT; failed = true; break; }
-                    // ---- violation of the row at the current point
-                    double sviol;
-                    if (lane <= F + 1) L.fl[lane] = fr;
-                    WAVE_LDS_SYNC();
-                    if (isZ) {
-                        double lc = 0.0, cm[RL], vv[RL];
+                    // ---- violation of the row at the current point (after a partial step)
+                    if (!fresh) {
+                        if (lane <= F + 1) L.fl[lane] = fr;
+                        WAVE_LDS_SYNC();
+                        if (isZ) {
+                            double lc = 0.0, cm[RL], vv[RL];
 #pragma unroll
-                        for (int k = 0; k < RL; ++k) { lc += u[k]; cm[k] = lc; }
-                        const double bs = wave_scan_up(lc) - lc;
+                            for (int k = 0; k < RL; ++k) { lc += u[k]; cm[k] = lc; }
+                            const double bs = wave_scan_up(lc) - lc;
 #pragma unroll
-                        for (int k = 0; k < RL; ++k) vv[k] = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + w2[k] * L.fl[k1[k] + 1]);
-                        const double v = at_row<RL>(vv, row);
-                        sviol = sg > 0.0 ? v - at_row<RL>(zlo, row) : at_row<RL>(zhi, row) - v;
-                    } else {
-                        const double fprev = dpp64<0x111, 0xf, true>(0.0, fr);
-                        const double vk = sg > 0.0 ? (fr - fprev) - klo : khi - (fr - fprev);
-                        sviol = sq * rl_d(vk, kr);
+                            for (int k = 0; k < RL; ++k) vv[k] = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + (1.0 - w1[k]) * L.fl[k1[k] + 1]);
+                            const double v = at_row<RL>(vv, row);
+                            const double m1 = (p_k1 == 0) ? p_w1 : 0.0;
+                            sviol = sg > 0.0 ? v - (zlo0 + m1 * cur) : (zhi0 + m1 * cur) - v;
+                        } else {
+                            const double fprev = dpp64<0x111, 0xf, true>(0.0, fr);
+                            const double vk = sg > 0.0 ? (fr - fprev) - klo : khi - (fr - fprev);
+                            sviol = sq * rl_d(vk, kr);
+                        }
                     }
+                    fresh = false;
                     // ---- neighbours (na < row < nb) of a new ZMP row among the active ones; V there
                     int na = 0, nb = 0; double th = 0.0, va = 0.0, vb = 0.0, vint = 0.0;
                     if (isZ && qz > 0) {
@@ -783,59 +791,63 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                             if (sta[k] != 0 && i > row) lb = min(lb, i);
                         }
                         na = wave_max_i(la); nb = wave_min_i(lb); if (nb == (1 << 30)) nb = 0;
-                        if (na > 0) { const int q1 = at_row<RL>(k1, na); const double q2 = at_row<RL>(w1, na), q3 = at_row<RL>(w2, na), q4 = at_row<RL>(pa, na);
-                                      if (lane < m) va = border_elem(lane, F, q1, q2, q3, q4, dt, isq); }
-                        if (nb > 0) { const int q1 = at_row<RL>(k1, nb); const double q2 = at_row<RL>(w1, nb), q3 = at_row<RL>(w2, nb), q4 = at_row<RL>(pa, nb);
-                                      if (lane < m) vb = border_elem(lane, F, q1, q2, q3, q4, dt, isq); }
+                        if (na > 0 && lane < m) va = border_elem<F>(lane, L.k1s[na - 1], L.w1s[na - 1], pa_s[na], dt, isq);
+                        if (nb > 0 && lane < m) vb = border_elem<F>(lane, L.k1s[nb - 1], L.w1s[nb - 1], pa_s[nb], dt, isq);
                         if (nb == 0) { vint = va; th = 0.0; }
                         else if (na == 0) { th = (double)row / (double)nb; vint = th * vb; }
                         else { th = (double)(row - na) / (double)(nb - na); vint = va + th * (vb - va); }
                     }
                     // ---- small quasi-definite system  [[I+G11, G1x],[Gx1, Gxx - Sxx]] cc = [h1 ; hx - dX]
                     // unknown order: 0..F-1 footstep columns, F = stability row, F+1..2F = Khat_1..F (inactive: pinned to 0)
-                    double h_e = 0.0;                                            // lane e: h[e] - dX[e]
                     if (lane < m) {
-                        h_e = sg * vint;
+                        double h_e = sg * vint;
+#pragma unroll
                         for (int r = 0; r < F; ++r) h_e += L.G[lane * m + r] * L.mt[r];
-                        h_e -= dx_e;
-                        L.hx[lane] = h_e;
+                        L.hx[lane] = h_e - dx_e;
                     }
                     WAVE_LDS_SYNC();
                     const unsigned long long kmask = __builtin_amdgcn_ballot_w64(klane && kact != 0);   // bit r: Khat_r active
-                    for (int e = lane; e < m * (m + 1); e += 64) {
-                        const int i = e / (m + 1), jj = e - i * (m + 1);
-                        const bool ipin = i > F && !((kmask >> (i - F)) & 1ull);
-                        const bool jpin = jj > F && jj < m && !((kmask >> (jj - F)) & 1ull);
-                        double val;
-                        if (jj < m) {
-                            val = L.G[i * m + jj];
-                            if (i < F && jj == i) val += 1.0;
-                            if (i == F && jj == F) val -= c.aa;
-                            if (i > F && jj > F) {
-                                const int r1 = i - F, r2 = jj - F;
-                                val -= (r1 == r2) ? (r1 >= 2 ? 2.0 : 1.0) : ((r1 - r2 == 1 || r2 - r1 == 1) ? -1.0 : 0.0);
-                            }
-                            if (ipin || jpin) val = (i == jj) ? -1.0 : 0.0;
-                        } else {
-                            val = ipin ? 0.0 : L.hx[i];
+#pragma unroll
+                    for (int s_ = 0; s_ < NE; ++s_) {
+                        const int e = lane + 64 * s_;
+                        if (e < NK) {
+                            const int i = e / (m + 1), jj = e - i * (m + 1);
+                            const bool ipin = i > F && !((kmask >> (i - F)) & 1ull);
+                            const bool jpin = jj > F && jj < m && !((kmask >> (jj - F)) & 1ull);
+                            double val;
+                            if (jj < m) {
+                                val = L.G[i * m + jj];
+                                if (i < F && jj == i) val += 1.0;
+                                if (i == F && jj == F) val -= c.aa;
+                                if (i > F && jj > F) {
+                                    const int r1 = i - F, r2 = jj - F;
+                                    val -= (r1 == r2) ? (r1 >= 2 ? 2.0 : 1.0) : ((r1 - r2 == 1 || r2 - r1 == 1) ? -1.0 : 0.0);
+                                }
+                                if (ipin || jpin) val = (i == jj) ? -1.0 : 0.0;
+                            } else val = ipin ? 0.0 : L.hx[i];
+                            L.K[0][e] = val;
                         }
-                        L.K[e] = val;
                     }
                     WAVE_LDS_SYNC();
+                    int cur_buf = 0;
+#pragma nounroll
                     for (int kk = 0; kk < m; ++kk) {                              // Gauss-Jordan, no pivoting (quasi-definite)
-                        const double ipv = 1.0 / L.K[kk * (m + 1) + kk];
-                        double upd[(MAXM * (MAXM + 1) + 63) / 64];
-                        int cnt = 0;
-                        for (int e = lane; e < m * (m + 1); e += 64, ++cnt) {
-                            const int i = e / (m + 1), jj = e - i * (m + 1);
-                            upd[cnt] = (i != kk && jj > kk) ? L.K[e] - L.K[i * (m + 1) + kk] * L.K[kk * (m + 1) + jj] * ipv : L.K[e];
+                        if (kk > F && !((kmask >> (kk - F)) & 1ull)) continue;    // pinned unknown: its column is already e_kk
+                        const double* Ks = L.K[cur_buf]; double* Kd = L.K[cur_buf ^ 1];
+                        const double ipv = 1.0 / Ks[kk * (m + 1) + kk];
+#pragma unroll
+                        for (int s_ = 0; s_ < NE; ++s_) {
+                            const int e = lane + 64 * s_;
+                            if (e < NK) {
+                                const int i = e / (m + 1), jj = e - i * (m + 1);
+                                Kd[e] = (i != kk && jj > kk) ? Ks[e] - Ks[i * (m + 1) + kk] * Ks[kk * (m + 1) + jj] * ipv : Ks[e];
+                            }
                         }
-                        WAVE_LDS_SYNC();
-                        cnt = 0;
-                        for (int e = lane; e < m * (m + 1); e += 64, ++cnt) L.K[e] = upd[cnt];
+                        cur_buf ^= 1;
                         WAVE_LDS_SYNC();
                     }
-                    const double cc_e = (lane < m) ? L.K[lane * (m + 1) + m] / L.K[lane * (m + 1) + lane] : 0.0;   // lane e: cc[e]
+                    const double* Kf = L.K[cur_buf];
+                    const double cc_e = (lane < m) ? Kf[lane * (m + 1) + m] / Kf[lane * (m + 1) + lane] : 0.0;   // lane e: cc[e]
                     if (lane < m) L.cc[lane] = cc_e;
                     WAVE_LDS_SYNC();
                     const double cE = L.cc[F];
@@ -855,7 +867,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
 #pragma unroll
                     for (int k = 0; k < RL; ++k) {
                         const int i = lane * RL + k + 1;
-                        svl[k] = (i <= C) ? (w1[k] * L.comb[k1[k]] + w2[k] * L.comb[k1[k] + 1]) - dt * pa[k] * cE : 0.0;
+                        svl[k] = (i <= C) ? (w1[k] * L.comb[k1[k]] + (1.0 - w1[k]) * L.comb[k1[k] + 1]) - dt * pa_s[i] * cE : 0.0;
                         if (i <= C) L.sv[i - 1] = svl[k];
                     }
                     WAVE_LDS_SYNC();
@@ -875,18 +887,19 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                                 if (i == nb) r_ += sg * th;
                             }
                             rho[k] = r_;
+                            const double w2k = 1.0 - w1[k];
                             double dj;                                             // sg <row+, Z_i>
                             if (isZ) {
                                 double mm = 0.0;                                   // M_p . M_i
                                 const int a1 = p_k1, b1 = k1[k];
-                                if (a1 >= 1) { if (a1 == b1) mm += p_w1 * w1[k]; else if (a1 == b1 + 1) mm += p_w1 * w2[k]; }
-                                { const int cx = a1 + 1; if (cx == b1 && b1 >= 1) mm += p_w2 * w1[k]; else if (cx == b1 + 1) mm += p_w2 * w2[k]; }
+                                if (a1 >= 1) { if (a1 == b1) mm += p_w1 * w1[k]; else if (a1 == b1 + 1) mm += p_w1 * w2k; }
+                                { const int cx = a1 + 1; if (cx == b1 && b1 >= 1) mm += p_w2 * w1[k]; else if (cx == b1 + 1) mm += p_w2 * w2k; }
                                 dj = sg * (dt * dt * (double)min(row, i) + mm / Qf);
                             } else {
                                 double mk = 0.0;                                   // M_i . kvec_kr
                                 if (k1[k] == kr) mk += w1[k];
-                                if (k1[k] + 1 == kr) mk += w2[k];
-                                if (kr - 1 >= 1) { if (k1[k] == kr - 1) mk -= w1[k]; if (k1[k] + 1 == kr - 1) mk -= w2[k]; }
+                                if (k1[k] + 1 == kr) mk += w2k;
+                                if (kr - 1 >= 1) { if (k1[k] == kr - 1) mk -= w1[k]; if (k1[k] + 1 == kr - 1) mk -= w2k; }
                                 dj = sg * (-mk) * isq;
                             }
                             ddl += dj * r_;
@@ -919,7 +932,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         const double incl = wave_scan_up(ls);
                         const double above = rl_d(incl, 63) - incl;               // lanes above this one
 #pragma unroll
-                        for (int k = 0; k < RL; ++k) u[k] += t * ((suf[k] + above) - cE * av[k]);
+                        for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; if (i <= C) u[k] += t * ((suf[k] + above) - cE * a_s[i - 1]); }
                         if (klane) {
                             // z_f[r] = ( n+_f[r] + sqrt(Qf) c1[r] - sqrt(Qf) (cK[r] - cK[r+1]) ) / Qf
                             const int r = lane;
@@ -940,8 +953,11 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         if (isZ) {
                             if (lane < m) { L.d1[lane] = vp - va; L.d2[lane] = (nb > 0 ? vb : 0.0) - vp; L.d0[lane] = (nb > 0 ? vb : 0.0) - va; }
                             WAVE_LDS_SYNC();
-                            gram_update(L, lane, m, 1.0, idt2 / (double)(row - na), nb > 0 ? idt2 / (double)(nb - row) : 0.0,
-                                        nb > 0 ? idt2 / (double)(nb - na) : 0.0);
+                            const double g1 = idt2 / (double)(row - na), g2 = nb > 0 ? idt2 / (double)(nb - row) : 0.0, g0 = nb > 0 ? idt2 / (double)(nb - na) : 0.0;
+                            for (int e = lane; e < m * m; e += 64) {
+                                const int i = e / m, jj = e - i * m;
+                                L.G[e] += g1 * L.d1[i] * L.d1[jj] + g2 * L.d2[i] * L.d2[jj] - g0 * L.d0[i] * L.d0[jj];
+                            }
                             WAVE_LDS_SYNC();
 #pragma unroll
                             for (int k = 0; k < RL; ++k) {
@@ -961,16 +977,18 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                     if (lrow <= C) {
                         const int pa_ = at_row<RL>(prv, lrow), pb_ = at_row<RL>(nxt, lrow);
                         double vl_ = 0.0, wa_ = 0.0, wb_ = 0.0;
-                        { const int q1 = at_row<RL>(k1, lrow); const double q2 = at_row<RL>(w1, lrow), q3 = at_row<RL>(w2, lrow), q4 = at_row<RL>(pa, lrow);
-                          if (lane < m) vl_ = border_elem(lane, F, q1, q2, q3, q4, dt, isq); }
-                        if (pa_ > 0) { const int q1 = at_row<RL>(k1, pa_); const double q2 = at_row<RL>(w1, pa_), q3 = at_row<RL>(w2, pa_), q4 = at_row<RL>(pa, pa_);
-                                       if (lane < m) wa_ = border_elem(lane, F, q1, q2, q3, q4, dt, isq); }
-                        if (pb_ > 0) { const int q1 = at_row<RL>(k1, pb_); const double q2 = at_row<RL>(w1, pb_), q3 = at_row<RL>(w2, pb_), q4 = at_row<RL>(pa, pb_);
-                                       if (lane < m) wb_ = border_elem(lane, F, q1, q2, q3, q4, dt, isq); }
-                        if (lane < m) { L.d1[lane] = vl_ - wa_; L.d2[lane] = (pb_ > 0 ? wb_ : 0.0) - vl_; L.d0[lane] = (pb_ > 0 ? wb_ : 0.0) - wa_; }
+                        if (lane < m) {
+                            vl_ = border_elem<F>(lane, L.k1s[lrow - 1], L.w1s[lrow - 1], pa_s[lrow], dt, isq);
+                            if (pa_ > 0) wa_ = border_elem<F>(lane, L.k1s[pa_ - 1], L.w1s[pa_ - 1], pa_s[pa_], dt, isq);
+                            if (pb_ > 0) wb_ = border_elem<F>(lane, L.k1s[pb_ - 1], L.w1s[pb_ - 1], pa_s[pb_], dt, isq);
+                            L.d1[lane] = vl_ - wa_; L.d2[lane] = (pb_ > 0 ? wb_ : 0.0) - vl_; L.d0[lane] = (pb_ > 0 ? wb_ : 0.0) - wa_;
+                        }
                         WAVE_LDS_SYNC();
-                        gram_update(L, lane, m, -1.0, idt2 / (double)(lrow - pa_), pb_ > 0 ? idt2 / (double)(pb_ - lrow) : 0.0,
-                                    pb_ > 0 ? idt2 / (double)(pb_ - pa_) : 0.0);
+                        const double g1 = idt2 / (double)(lrow - pa_), g2 = pb_ > 0 ? idt2 / (double)(pb_ - lrow) : 0.0, g0 = pb_ > 0 ? idt2 / (double)(pb_ - pa_) : 0.0;
+                        for (int e = lane; e < m * m; e += 64) {
+                            const int i = e / m, jj = e - i * m;
+                            L.G[e] -= g1 * L.d1[i] * L.d1[jj] + g2 * L.d2[i] * L.d2[jj] - g0 * L.d0[i] * L.d0[jj];
+                        }
                         WAVE_LDS_SYNC();
 #pragma unroll
                         for (int k = 0; k < RL; ++k) {
@@ -1016,6 +1034,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 else { o->iters_y = iters; atomicOr(&o->status, status); atomicOr(&o->active, (q & 0xffff) << 16); }
             }
         }
+        WAVE_LDS_SYNC();
     }
 }
 
@@ -1290,9 +1309,12 @@ int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state
         const int rl = (h->c.C + 63) / 64;
         const int grid = std::min((2 * batch + 3) / 4, h->wave_blocks);
         const ismpc_a_state* prev = h->prev;
-#define ISMPC_A_W(RL_) hipLaunchKernelGGL((ismpc_a_tick_wave<RL_>), dim3(grid), dim3(T), 0, s, h->c, prev, state_dev, push_dev, out_dev, batch)
+#define ISMPC_A_W(RL_, F_) hipLaunchKernelGGL((ismpc_a_tick_wave<RL_, F_>), dim3(grid), dim3(T), 0, s, h->c, prev, state_dev, push_dev, out_dev, batch)
+#define ISMPC_A_WF(RL_) do { switch (h->c.F) { case 3: ISMPC_A_W(RL_, 3); break; case 4: ISMPC_A_W(RL_, 4); break; \
+                                               case 5: ISMPC_A_W(RL_, 5); break; case 6: ISMPC_A_W(RL_, 6); break; default: launched = false; } } while (0)
         bool launched = true;
-        switch (rl) { case 1: case 2: ISMPC_A_W(2); break; case 3: ISMPC_A_W(3); break; case 4: ISMPC_A_W(4); break; default: launched = false; }
+        switch (rl) { case 1: case 2: ISMPC_A_WF(2); break; case 3: ISMPC_A_WF(3); break; case 4: ISMPC_A_WF(4); break; default: launched = false; }
+#undef ISMPC_A_WF
 #undef ISMPC_A_W
         if (launched) { HIP_TRY_A(hipGetLastError()); return 0; }
     }
