@@ -15,8 +15,9 @@
  *                                 footstep counter + plan shift + centreline rebuild)
  *   ismpc_a_rollout_device  <->  the whole loop, closed on the device
  *
- * The swing-foot re-placement QPs (quad_walk_no_plots.m:336-504) edit foot_plan only and are not part of
- * this ABI.  Conventions as ismpc.h: plain C, int status, no CPU fallback.
+ * The swing-foot re-placement QPs, the foot trajectories and the text wire format are the
+ * ismpc_a_*feet* / ismpc_a_foot_trajectories / ismpc_a_write_trajectory_txt entry points further down.
+ * Conventions as ismpc.h: plain C, int status, no CPU fallback.
  */
 #ifndef ISMPC_A_H
 #define ISMPC_A_H
@@ -101,6 +102,30 @@ int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state
 /* `ticks` ticks, out_traj NULL or ticks x batch records. */
 int ismpc_a_rollout_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, int ticks,
                            ismpc_a_out* out_traj_dev, void* stream);
+
+/* ---- swing-foot re-placement (the scripts' second quadprog) and the trajectory wire format -------------------
+ *   ismpc_a_feet_init_device / ismpc_a_tick_feet_batch_device / ismpc_a_rollout_feet_device
+ *        <->  trotting/quad_as_bip_no_plots.m:332-426 + compute_two_feet1.m:1-56
+ *             walking/quad_walk_no_plots.m:336-504   + compute_one_feet_walk.m:84-140
+ *   ismpc_a_foot_trajectories   <->  quad_as_bip_no_plots.m:482-509 / quad_walk_no_plots.m:562-613
+ *   ismpc_a_write_trajectory_txt <-> fprintf(file, '%d %d %d\n', row)   (what Controller.cpp:147-281 reads back)
+ * Every instance carries its own foot_plan: feet_dev is batch x ismpc_a_feet_rows(h) x 8 doubles
+ * (columns BL, BR, FR, FL xy).                                                                           */
+#define ISMPC_A_FEET_PAD 8                           /* feet_dev rows per instance = plan rows + ISMPC_A_FEET_PAD   */
+int ismpc_a_feet_rows(const ismpc_a_handle* h);     /* rows per instance in feet_dev, once initialised             */
+int ismpc_a_feet_init_device(ismpc_a_handle* h, const ismpc_a_gait* g, const double* foot_plan_host, int rows,
+                             int batch, double* feet_dev, void* stream);
+/* one tick (as ismpc_a_tick_batch_device) followed by the foot QP of every instance */
+int ismpc_a_tick_feet_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const double* push_dev,
+                                   ismpc_a_out* out_dev, double* feet_dev, void* stream);
+int ismpc_a_rollout_feet_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, int ticks,
+                                ismpc_a_out* out_traj_dev, double* feet_dev, void* stream);
+/* Host: the four foot files of one instance.  foot_plan: rows x 8 (as left by the rollout); dst: 4 x n x 3 in the
+ * order fl, fr, rl, rr with n = (sim_duration / step) * step rows; returns n. */
+int ismpc_a_foot_trajectories(const ismpc_a_gait* g, int step, const double* foot_plan, int rows, int sim_duration, double* dst);
+/* Host: write n rows of 3 values exactly as MATLAB's fprintf(file, '%d %d %d\n', row) does (integers as %d,
+ * everything else as %e).  Returns 0 or a negative error. */
+int ismpc_a_write_trajectory_txt(const char* path, const double* rows3, int n);
 
 const char* ismpc_a_last_error(void);
 

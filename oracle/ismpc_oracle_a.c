@@ -77,6 +77,10 @@ typedef struct orc_a_sim {
     double A_upd[9], B_upd[3];
     orc_a_state st;
     orc_qp_fn qp;
+    /* swing-foot re-placement (second quadprog of the scripts): optional, enabled by orc_a_enable_feet */
+    double* fp;                    /* foot_plan, (fprows+2) x 8, 1-based rows, columns BL(1,2) BR(3,4) FR(5,6) FL(7,8) */
+    int fprows, gait, counter;     /* `counter` of quad_walk_no_plots.m:114 (incremented with fsCounter, never wrapped) */
+    double phi, disp_i, disp_o, disp_forw_feet;
 } orc_a_sim;
 
 /* ---- helpers ---------------------------------------------------------- */
@@ -221,7 +225,7 @@ static void build_centerline(orc_a_sim* s, int initial)
 void orc_a_destroy(orc_a_sim* s)
 {
     if (!s) return;
-    free(s->fsx); free(s->fsy); free(s->clx); free(s->cly); free(s);
+    free(s->fsx); free(s->fsy); free(s->clx); free(s->cly); free(s->fp); free(s);
 }
 
 /* center: (n_gait+1) x 2, rows 1..n_gait (as orc_a_plan writes it) */
@@ -372,6 +376,147 @@ int orc_a_axis_data(orc_a_sim* s, int axis, double* a, double* b, double* zlo, d
     return 0;
 }
 
+
+/* ---- swing-foot re-placement: trotting/quad_as_bip_no_plots.m:332-426 + compute_two_feet1.m,
+ *                               walking/quad_walk_no_plots.m:336-504 + compute_one_feet_walk.m:84-140 ---- */
+void orc_a_enable_feet(orc_a_sim* s, const orc_a_gait* g, const double* foot_plan /* rows x 8, 0-based rows = MATLAB row-1 */, int rows)
+{
+    free(s->fp);
+    s->fprows = rows;
+    s->fp = (double*)calloc((size_t)(rows + 12) * 8, 8);
+    memcpy(s->fp + 8, foot_plan, sizeof(double) * (size_t)rows * 8);
+    for (int r = rows + 1; r < rows + 12; ++r) memcpy(s->fp + (size_t)r * 8, foot_plan + (size_t)(rows - 1) * 8, 64);   /* MATLAB would auto-grow; never read */
+    s->gait = g->gait; s->phi = g->phi; s->disp_i = g->disp_i; s->disp_o = g->disp_o; s->disp_forw_feet = g->disp_forw;
+    s->counter = 1;
+}
+int orc_a_foot_rows(const orc_a_sim* s) { return s->fprows; }
+void orc_a_get_foot_plan(const orc_a_sim* s, double* dst) { memcpy(dst, s->fp + 8, sizeof(double) * (size_t)s->fprows * 8); }
+
+#define FPL(r, c) s->fp[(size_t)(r) * 8 + ((c) - 1)]
+/* line through the two fixed feet, the line of opposite slope through the predicted footstep centre ("zmp"),
+ * their intersection; returns slope m of the fixed diagonal, (dist_x, dist_y) = zmp - intersection */
+static void fixed_diagonal(double fx1, double fy1, double fx2, double fy2, double zx, double zy, double* m, double* dx, double* dy)
+{
+    const double mm = (fy2 - fy1) / (fx2 - fx1), q = fy1 - mm * fx1;           /* polyfit(...,1) on two points */
+    const double xi = (zy + mm * zx - q) / (2 * mm), yi = mm * xi + q;
+    *m = mm; *dx = zx - xi; *dy = zy - yi;
+}
+static double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static void foot_tick_trot(orc_a_sim* s, int fc, double zx, double zy)
+{
+    const double di = s->disp_i, dobd = s->disp_o, df = s->disp_forw_feet;
+    const int odd = (fc % 2) == 1;
+    /* moving pair at row fc+1: odd -> BL(1,2), FR(5,6) ; even -> BR(3,4), FL(7,8).  fixed pair at row fc: the other two */
+    const int f1 = odd ? 3 : 1, f2 = odd ? 7 : 5, m1 = odd ? 1 : 3, m2 = odd ? 5 : 7;
+    double m, dx, dy;
+    fixed_diagonal(FPL(fc, f1), FPL(fc, f1 + 1), FPL(fc, f2), FPL(fc, f2 + 1), zx, zy, &m, &dx, &dy);
+    double x1, y1, x2, y2;
+    const double fr1x = FPL(fc + 1, m1), fr1y = FPL(fc + 1, m1 + 1), fr2x = FPL(fc + 1, m2), fr2y = FPL(fc + 1, m2 + 1);
+    if (s->phi == 3.14159265358979323846 / 2) {
+        x1 = fr1x; x2 = fr2x;
+        y1 = zy - m * (x1 - zx); y2 = zy - m * (x2 - zx);
+    } else {
+        const double tp = tan(s->phi);
+        x1 = (zy + m * zx - fr1y + tp * fr1x) / (tp + m); y1 = tp * (x1 - fr1x) + fr1y;
+        x2 = (zy + m * zx - fr2y + tp * fr2x) / (tp + m); y2 = tp * (x2 - fr2x) + fr2y;
+    }
+    if (dy != 0 || dx != 0) {                                                  /* changed: foot_plan(fc+1,:) = quattro_piedi */
+        FPL(fc + 1, m1) = x1; FPL(fc + 1, m1 + 1) = y1; FPL(fc + 1, m2) = x2; FPL(fc + 1, m2 + 1) = y2;
+        FPL(fc + 1, f1) = FPL(fc, f1); FPL(fc + 1, f1 + 1) = FPL(fc, f1 + 1); FPL(fc + 1, f2) = FPL(fc, f2); FPL(fc + 1, f2 + 1) = FPL(fc, f2 + 1);
+    }
+    /* quadprog(eye(4), -target, A, b): separable, so the minimiser is the projection on the box */
+    const double lim_o = (fc == 1) ? dobd / 2 : dobd, lim_i = (fc == 1) ? di / 2 : di, lim_f = (fc == 1) ? df / 2 : df;
+    /* first foot of the pair: y in [y_prev - disp_i, y_prev + disp_o], x <= x_prev + disp_forw ; second: y in [y_prev - disp_o, y_prev + disp_i] */
+    {
+        const double px = FPL(fc, m1), py = FPL(fc, m1 + 1);
+        FPL(fc + 1, m1 + 1) = clipd(FPL(fc + 1, m1 + 1), py - lim_i, py + lim_o);
+        if (FPL(fc + 1, m1) > px + lim_f) FPL(fc + 1, m1) = px + lim_f;
+    }
+    {
+        const double px = FPL(fc, m2), py = FPL(fc, m2 + 1);
+        FPL(fc + 1, m2 + 1) = clipd(FPL(fc + 1, m2 + 1), py - lim_o, py + lim_i);
+        if (FPL(fc + 1, m2) > px + lim_f) FPL(fc + 1, m2) = px + lim_f;
+    }
+}
+
+static void foot_tick_walk(orc_a_sim* s, int fc, double zx, double zy)
+{
+    const int counter = s->counter;
+    if (!(counter == 2 || counter == 4 || counter == 6 || counter == 8)) return;
+    const double di = s->disp_i, dobd = s->disp_o, df = s->disp_forw_feet;
+    /* moving foot column, the two "fixed" feet whose diagonal is used (first two pairs of the `fixed` argument) */
+    int mc, a1, a2; int outer_up;                       /* outer_up: upper y bound uses disp_o (left feet) else disp_i */
+    if (counter == 2)      { mc = 7; a1 = 1; a2 = 5; outer_up = 1; }        /* FL moves; fixed = BL, FR, BR */
+    else if (counter == 4) { mc = 3; a1 = 1; a2 = 5; outer_up = 0; }        /* BR moves; fixed = BL, FR, FL */
+    else if (counter == 6) { mc = 5; a1 = 3; a2 = 7; outer_up = 0; }        /* FR moves; fixed = BR, FL, BL */
+    else                   { mc = 1; a1 = 3; a2 = 7; outer_up = 1; }        /* BL moves; fixed = BR, FL, FR */
+    double m, dx, dy;
+    fixed_diagonal(FPL(fc, a1), FPL(fc, a1 + 1), FPL(fc, a2), FPL(fc, a2 + 1), zx, zy, &m, &dx, &dy);
+    const double xfree = FPL(fc + 1, mc) + dx, yfree = FPL(fc + 1, mc + 1) + dy;
+    if (dy != 0 || dx != 0)
+        for (int l = 1; l <= 8; ++l) { FPL(fc + l, mc) = xfree; FPL(fc + l, mc + 1) = yfree; }
+    const int dummy = (counter == 2 || counter == 4) && fc <= 4;
+    const double lo_ = dummy ? dobd / 2 : dobd, li_ = dummy ? di / 2 : di, lf_ = dummy ? df / 2 : df;
+    const double px = FPL(fc, mc), py = FPL(fc, mc + 1);
+    double X1 = FPL(fc + 1, mc), X2 = FPL(fc + 1, mc + 1);
+    if (outer_up) X2 = clipd(X2, py - li_, py + lo_); else X2 = clipd(X2, py - lo_, py + li_);
+    if (X1 > px + lf_) X1 = px + lf_;
+    if (counter == 8) {                                  /* quad_walk_no_plots.m:498-503: the y write-back only touches row fc+1 */
+        for (int l = 1; l <= 8; ++l) FPL(fc + l, mc) = X1;
+        FPL(fc + 1, mc + 1) = X2;
+    } else {
+        for (int l = 1; l <= 8; ++l) { FPL(fc + l, mc) = X1; FPL(fc + l, mc + 1) = X2; }
+    }
+}
+#undef FPL
+
+/* foot_*.txt rows (quad_as_bip_no_plots.m:482-509 / quad_walk_no_plots.m:562-613): dst = 4 x nrows x 3, order fl, fr, rl, rr */
+int orc_a_foot_trajectories(const orc_a_sim* s, int sim_duration, double* dst)
+{
+    const int step = s->p.step, nsteps = sim_duration / step, nrows = nsteps * step;
+    int row = 0, cont = 1;
+#define FPL(r, c) s->fp[(size_t)(r) * 8 + ((c) - 1)]
+#define PUT(foot, X, Y, Z) do { double* d_ = dst + ((size_t)(foot) * nrows + row) * 3; d_[0] = (X); d_[1] = (Y); d_[2] = (Z); } while (0)
+    for (int i = 1; i <= nsteps; ++i) {
+        if (s->gait == 0) {
+            const int hold = step - 50;                                           /* the script hard-codes 30 + 50 */
+            for (int k = 1; k <= hold; ++k) {
+                PUT(0, FPL(i,7), FPL(i,8), 0.0); PUT(3, FPL(i,3), FPL(i,4), 0.0); PUT(1, FPL(i,5), FPL(i,6), 0.0); PUT(2, FPL(i,1), FPL(i,2), 0.0); ++row;
+            }
+            for (int j = 1; j <= 50; ++j) {
+                const double z = -0.000032 * j * j + 0.0016 * j;
+                if (i % 2 == 1) {
+                    PUT(0, FPL(i,7), FPL(i,8), 0.0); PUT(3, FPL(i,3), FPL(i,4), 0.0);
+                    PUT(2, FPL(i,1) + (FPL(i+1,1) - FPL(i,1)) / 50 * j, FPL(i,2) + (FPL(i+1,2) - FPL(i,2)) / 50 * j, z);
+                    PUT(1, FPL(i,5) + (FPL(i+1,5) - FPL(i,5)) / 50 * j, FPL(i,6) + (FPL(i+1,6) - FPL(i,6)) / 50 * j, z);
+                } else {
+                    PUT(2, FPL(i,1), FPL(i,2), 0.0); PUT(1, FPL(i,5), FPL(i,6), 0.0);
+                    PUT(0, FPL(i,7) + (FPL(i+1,7) - FPL(i,7)) / 50 * j, FPL(i,8) + (FPL(i+1,8) - FPL(i,8)) / 50 * j, z);
+                    PUT(3, FPL(i,3) + (FPL(i+1,3) - FPL(i,3)) / 50 * j, FPL(i,4) + (FPL(i+1,4) - FPL(i,4)) / 50 * j, z);
+                }
+                ++row;
+            }
+        } else {
+            for (int k = 1; k <= step; ++k) {
+                const double z = -0.000032 * k * k + 0.0016 * k;
+                const int mv = (cont == 2) ? 7 : (cont == 4) ? 3 : (cont == 6) ? 5 : (cont == 8) ? 1 : 0;
+                const int cols[4] = {7, 5, 1, 3};                                 /* fl, fr, rl, rr */
+                for (int ft = 0; ft < 4; ++ft) {
+                    const int cc = cols[ft];
+                    if (cc == mv) PUT(ft, FPL(i,cc) + (FPL(i+1,cc) - FPL(i,cc)) / step * k, FPL(i,cc+1) + (FPL(i+1,cc+1) - FPL(i,cc+1)) / step * k, z);
+                    else PUT(ft, FPL(i,cc), FPL(i,cc+1), 0.0);
+                }
+                ++row;
+            }
+            cont = (cont == 8) ? 1 : cont + 1;
+        }
+    }
+#undef PUT
+#undef FPL
+    return nrows;
+}
+
 /* One iteration of `for j = 1:sim_duration` (push = impulsive velocity disturbance added first, :134-148). */
 int orc_a_tick(orc_a_sim* s, double push_x, double push_y, orc_a_tick_out* out, double* sol_x, double* sol_y)
 {
@@ -426,9 +571,15 @@ int orc_a_tick(orc_a_sim* s, double push_x, double push_y, orc_a_tick_out* out, 
     }
     out->vel_after[0] = s->st.xd; out->vel_after[1] = s->st.yd;       /* xd_store(j), yd_store(j) */
 
+    /* second quadprog: swing feet of the NEXT footstep row (uses this tick's predicted footstep and the old fsCounter) */
+    if (s->fp && fc + 9 <= s->fprows + 10) {
+        if (s->gait == 0) foot_tick_trot(s, fc, s->st.pred_x, s->st.pred_y);
+        else foot_tick_walk(s, fc, s->st.pred_x, s->st.pred_y);
+    }
     /* footstep bookkeeping, :522-556 */
     if (j + 1 >= fs_timing(s, fc + 1)) {
         const int nfc = fc + 1;
+        s->counter += 1;                                                 /* quad_walk_no_plots.m:527 */
         s->st.fc = nfc;
         s->st.cur_x = s->st.pred_x; s->st.cur_y = s->st.pred_y;
         const double dx = s->st.pred_x - s->fsx[nfc], dy = s->st.pred_y - s->fsy[nfc];

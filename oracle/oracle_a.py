@@ -67,6 +67,10 @@ def _lib():
         lib.orc_a_tick.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.orc_a_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.orc_a_axis_data.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
+        lib.orc_a_enable_feet.argtypes = [C.c_void_p, C.POINTER(Gait), C.c_void_p, C.c_int]
+        lib.orc_a_foot_rows.argtypes = [C.c_void_p]
+        lib.orc_a_get_foot_plan.argtypes = [C.c_void_p, C.c_void_p]
+        lib.orc_a_foot_trajectories.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib._a_ready = True
     return lib
 
@@ -108,6 +112,25 @@ class SimA:
         _lib().orc_a_tick(self._h, float(push[0]), float(push[1]), out.ctypes.data_as(C.c_void_p),
                           sx.ctypes.data_as(C.c_void_p), sy.ctypes.data_as(C.c_void_p))
         return (out[0], sx, sy) if want_solution else out[0]
+
+    def enable_feet(self):
+        """Turn on the swing-foot re-placement QPs (second quadprog of the scripts) for this run."""
+        fp = np.zeros((self.g.n_gait + 2, 8)); ce = np.zeros((self.g.n_gait + 1, 2))
+        used = _lib().orc_a_plan(C.byref(self.g), fp.ctypes.data_as(C.c_void_p), ce.ctypes.data_as(C.c_void_p))
+        self._fp0 = np.ascontiguousarray(fp[1:used + 1])
+        _lib().orc_a_enable_feet(self._h, C.byref(self.g), self._fp0.ctypes.data_as(C.c_void_p), used)
+
+    def foot_plan(self):
+        n = _lib().orc_a_foot_rows(self._h)
+        fp = np.zeros((n, 8)); _lib().orc_a_get_foot_plan(self._h, fp.ctypes.data_as(C.c_void_p))
+        return fp
+
+    def foot_trajectories(self, sim_duration=2000):
+        """foot_{fl,fr,rl,rr}_*.txt contents: array [4, rows, 3]."""
+        rows = (sim_duration // self.p.step) * self.p.step
+        out = np.zeros((4, rows, 3))
+        _lib().orc_a_foot_trajectories(self._h, sim_duration, out.ctypes.data_as(C.c_void_p))
+        return out
 
     def axis_data(self, axis):
         """Structured per-axis QP of the NEXT tick: dict(a, b, zlo, zhi, M [C, F+1], klo, khi, pref)."""

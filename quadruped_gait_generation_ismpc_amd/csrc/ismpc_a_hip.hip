@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
 #include <string>
 #include <vector>
 #include <new>
@@ -1038,6 +1039,90 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
     }
 }
 
+
+// ---- swing-foot re-placement: one thread per instance (closed forms; the 2-/4-variable quadprog is separable, so its
+// minimiser is the projection of the target on the box).  trotting/quad_as_bip_no_plots.m:332-426 + compute_two_feet1.m,
+// walking/quad_walk_no_plots.m:336-504 + compute_one_feet_walk.m:84-140.
+struct FeetParams { int gait, rows; double phi, disp_i, disp_o, disp_forw; };
+
+__device__ __forceinline__ void fixed_diagonal(double fx1, double fy1, double fx2, double fy2, double zx, double zy,
+                                               double& m, double& dx, double& dy)
+{
+    m = (fy2 - fy1) / (fx2 - fx1);
+    const double q = fy1 - m * fx1;
+    const double xi = (zy + m * zx - q) / (2 * m), yi = m * xi + q;
+    dx = zx - xi; dy = zy - yi;
+}
+__device__ __forceinline__ double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ void ismpc_a_feet_kernel(const FeetParams fpz, const ismpc_a_state* __restrict__ prev, const ismpc_a_out* __restrict__ out,
+                                    double* __restrict__ feet, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    if (out[b].status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) return;
+    const int fc = prev[b].fc;                                   // the fsCounter this tick ran with
+    if (fc < 1 || fc + 8 >= fpz.rows) return;
+    double* fp = feet + (size_t)b * fpz.rows * 8;
+#define FPL(r, c) fp[(size_t)((r) - 1) * 8 + ((c) - 1)]
+    const double zx = out[b].f0[0], zy = out[b].f0[1];           // predicted_xfs(1), predicted_yfs(1)
+    const double di = fpz.disp_i, dob = fpz.disp_o, df = fpz.disp_forw;
+    if (fpz.gait == 0) {
+        const bool odd = (fc % 2) == 1;
+        const int f1 = odd ? 3 : 1, f2 = odd ? 7 : 5, m1 = odd ? 1 : 3, m2 = odd ? 5 : 7;
+        double m, dx, dy;
+        fixed_diagonal(FPL(fc, f1), FPL(fc, f1 + 1), FPL(fc, f2), FPL(fc, f2 + 1), zx, zy, m, dx, dy);
+        const double a1x = FPL(fc + 1, m1), a1y = FPL(fc + 1, m1 + 1), a2x = FPL(fc + 1, m2), a2y = FPL(fc + 1, m2 + 1);
+        double x1, y1, x2, y2;
+        if (fpz.phi == 3.14159265358979323846 / 2) {
+            x1 = a1x; x2 = a2x; y1 = zy - m * (x1 - zx); y2 = zy - m * (x2 - zx);
+        } else {
+            const double tp = tan(fpz.phi);
+            x1 = (zy + m * zx - a1y + tp * a1x) / (tp + m); y1 = tp * (x1 - a1x) + a1y;
+            x2 = (zy + m * zx - a2y + tp * a2x) / (tp + m); y2 = tp * (x2 - a2x) + a2y;
+        }
+        if (dy != 0 || dx != 0) {
+            FPL(fc + 1, m1) = x1; FPL(fc + 1, m1 + 1) = y1; FPL(fc + 1, m2) = x2; FPL(fc + 1, m2 + 1) = y2;
+            FPL(fc + 1, f1) = FPL(fc, f1); FPL(fc + 1, f1 + 1) = FPL(fc, f1 + 1); FPL(fc + 1, f2) = FPL(fc, f2); FPL(fc + 1, f2 + 1) = FPL(fc, f2 + 1);
+        }
+        const double lo_ = (fc == 1) ? dob / 2 : dob, li_ = (fc == 1) ? di / 2 : di, lf_ = (fc == 1) ? df / 2 : df;
+        { const double px = FPL(fc, m1), py = FPL(fc, m1 + 1);
+          FPL(fc + 1, m1 + 1) = clipd(FPL(fc + 1, m1 + 1), py - li_, py + lo_);
+          if (FPL(fc + 1, m1) > px + lf_) FPL(fc + 1, m1) = px + lf_; }
+        { const double px = FPL(fc, m2), py = FPL(fc, m2 + 1);
+          FPL(fc + 1, m2 + 1) = clipd(FPL(fc + 1, m2 + 1), py - lo_, py + li_);
+          if (FPL(fc + 1, m2) > px + lf_) FPL(fc + 1, m2) = px + lf_; }
+    } else {
+        const int counter = fc;                                  // `counter` (quad_walk_no_plots.m:114,527) starts at 1 and moves with fsCounter
+        if (!(counter == 2 || counter == 4 || counter == 6 || counter == 8)) return;
+        int mc, a1, a2; bool outer_up;
+        if (counter == 2)      { mc = 7; a1 = 1; a2 = 5; outer_up = true; }
+        else if (counter == 4) { mc = 3; a1 = 1; a2 = 5; outer_up = false; }
+        else if (counter == 6) { mc = 5; a1 = 3; a2 = 7; outer_up = false; }
+        else                   { mc = 1; a1 = 3; a2 = 7; outer_up = true; }
+        double m, dx, dy;
+        fixed_diagonal(FPL(fc, a1), FPL(fc, a1 + 1), FPL(fc, a2), FPL(fc, a2 + 1), zx, zy, m, dx, dy);
+        const double xfree = FPL(fc + 1, mc) + dx, yfree = FPL(fc + 1, mc + 1) + dy;
+        if (dy != 0 || dx != 0)
+            for (int l = 1; l <= 8; ++l) { FPL(fc + l, mc) = xfree; FPL(fc + l, mc + 1) = yfree; }
+        const bool dummy = (counter == 2 || counter == 4) && fc <= 4;
+        const double lo_ = dummy ? dob / 2 : dob, li_ = dummy ? di / 2 : di, lf_ = dummy ? df / 2 : df;
+        const double px = FPL(fc, mc), py = FPL(fc, mc + 1);
+        double X1 = FPL(fc + 1, mc), X2 = FPL(fc + 1, mc + 1);
+        X2 = outer_up ? clipd(X2, py - li_, py + lo_) : clipd(X2, py - lo_, py + li_);
+        if (X1 > px + lf_) X1 = px + lf_;
+        if (counter == 8) { for (int l = 1; l <= 8; ++l) FPL(fc + l, mc) = X1; FPL(fc + 1, mc + 1) = X2; }    // :498-503 as written
+        else for (int l = 1; l <= 8; ++l) { FPL(fc + l, mc) = X1; FPL(fc + l, mc + 1) = X2; }
+    }
+#undef FPL
+}
+
+__global__ void ismpc_a_feet_fill(const double* __restrict__ base, double* __restrict__ feet, int rows, int batch)
+{
+    const size_t n = (size_t)batch * rows * 8;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) feet[e] = base[e % ((size_t)rows * 8)];
+}
+
 __global__ void ismpc_a_clear_out(ismpc_a_out* out, int batch)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1083,6 +1168,7 @@ struct ismpc_a_handle {
     DevA c{};
     int device = 0, slots = 0;
     ismpc_a_state* prev = nullptr; int prev_cap = 0;     // copy of the state the tick reads
+    FeetParams feet{}; double* feet_base = nullptr;     // swing-foot QPs (ismpc_a_feet_init_device)
     bool use_wave = true; int wave_blocks = 0;           // structured wavefront-per-QP kernel (default) vs workgroup-per-QP
     std::vector<void*> allocs;
     std::vector<double> fsx, fsy;
@@ -1276,6 +1362,7 @@ void ismpc_a_destroy(ismpc_a_handle* h)
     (void)hipSetDevice(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->prev) (void)hipFree(h->prev);
+    if (h->feet_base) (void)hipFree(h->feet_base);
     delete h;
 }
 
@@ -1321,6 +1408,108 @@ int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state
     const int grid = std::min(2 * batch, h->slots);
     hipLaunchKernelGGL(ismpc_a_tick_kernel, dim3(grid), dim3(T), h->c.sinv_in_lds ? (size_t)h->c.ldq * h->c.ldq * sizeof(double) : 0, s, h->c, (const ismpc_a_state*)h->prev, state_dev, push_dev, out_dev, batch);
     HIP_TRY_A(hipGetLastError());
+    return 0;
+}
+
+int ismpc_a_feet_rows(const ismpc_a_handle* h) { return h ? h->feet.rows : -1; }
+
+int ismpc_a_feet_init_device(ismpc_a_handle* h, const ismpc_a_gait* g, const double* foot_plan_host, int rows, int batch,
+                             double* feet_dev, void* stream)
+{
+    if (!h || !g || !foot_plan_host || rows < 2 || batch < 0 || (batch > 0 && !feet_dev)) return fail_a(-1, "bad argument");
+    HIP_TRY_A(hipSetDevice(h->device));
+    const int rp = rows + 8;                                       // the walk script writes rows fc+1 .. fc+8
+    std::vector<double> base((size_t)rp * 8);
+    for (int r = 0; r < rp; ++r) std::memcpy(&base[(size_t)r * 8], foot_plan_host + (size_t)std::min(r, rows - 1) * 8, 64);
+    if (h->feet_base) { (void)hipFree(h->feet_base); h->feet_base = nullptr; }
+    HIP_TRY_A(hipMalloc((void**)&h->feet_base, base.size() * sizeof(double)));
+    HIP_TRY_A(hipMemcpy(h->feet_base, base.data(), base.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->feet.gait = g->gait; h->feet.rows = rp; h->feet.phi = g->phi; h->feet.disp_i = g->disp_i; h->feet.disp_o = g->disp_o; h->feet.disp_forw = g->disp_forw;
+    if (batch > 0) {
+        hipLaunchKernelGGL(ismpc_a_feet_fill, dim3(std::min(1024, (batch * rp * 8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           (const double*)h->feet_base, feet_dev, rp, batch);
+        HIP_TRY_A(hipGetLastError());
+    }
+    return 0;
+}
+
+int ismpc_a_tick_feet_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const double* push_dev,
+                                   ismpc_a_out* out_dev, double* feet_dev, void* stream)
+{
+    if (!h || !out_dev || (batch > 0 && !feet_dev) || h->feet.rows == 0) return fail_a(-1, "feet: call ismpc_a_feet_init_device first and pass an output buffer");
+    int rc = ismpc_a_tick_batch_device(h, batch, state_dev, push_dev, out_dev, stream);
+    if (rc || batch == 0) return rc;
+    hipLaunchKernelGGL(ismpc_a_feet_kernel, dim3((batch + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       h->feet, (const ismpc_a_state*)h->prev, (const ismpc_a_out*)out_dev, feet_dev, batch);
+    HIP_TRY_A(hipGetLastError());
+    return 0;
+}
+
+int ismpc_a_rollout_feet_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, int ticks, ismpc_a_out* out_traj_dev,
+                                double* feet_dev, void* stream)
+{
+    if (!h || !out_traj_dev || batch < 0 || ticks < 0) return fail_a(-1, "bad argument");
+    for (int t = 0; t < ticks; ++t) {
+        int rc = ismpc_a_tick_feet_batch_device(h, batch, state_dev, nullptr, out_traj_dev + (size_t)t * batch, feet_dev, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// quad_as_bip_no_plots.m:482-509 / quad_walk_no_plots.m:562-613 (host)
+int ismpc_a_foot_trajectories(const ismpc_a_gait* g, int step, const double* foot_plan, int rows, int sim_duration, double* dst)
+{
+    if (!g || !foot_plan || !dst || step < 1 || sim_duration < step) return fail_a(-1, "bad argument");
+    const int nsteps = sim_duration / step, n = nsteps * step;
+    if (nsteps + 1 > rows) return fail_a(-1, "foot_plan has too few rows for this duration");
+    auto FPL = [&](int r, int c) { return foot_plan[(size_t)(r - 1) * 8 + (c - 1)]; };
+    auto put = [&](int foot, int row, double x, double y, double z) { double* d = dst + ((size_t)foot * n + row) * 3; d[0] = x; d[1] = y; d[2] = z; };
+    int row = 0, cont = 1;
+    for (int i = 1; i <= nsteps; ++i) {
+        if (g->gait == 0) {
+            if (step <= 50) return fail_a(-1, "the trot writer assumes step_duration > 50 (30 + 50 rows per step)");
+            for (int k = 1; k <= step - 50; ++k, ++row) {
+                put(0, row, FPL(i,7), FPL(i,8), 0.0); put(3, row, FPL(i,3), FPL(i,4), 0.0); put(1, row, FPL(i,5), FPL(i,6), 0.0); put(2, row, FPL(i,1), FPL(i,2), 0.0);
+            }
+            for (int j = 1; j <= 50; ++j, ++row) {
+                const double z = -0.000032 * j * j + 0.0016 * j;
+                const int still1 = (i % 2 == 1) ? 7 : 1, still2 = (i % 2 == 1) ? 3 : 5, mv1 = (i % 2 == 1) ? 1 : 7, mv2 = (i % 2 == 1) ? 5 : 3;
+                const int footOf[9] = {0, 2, 0, 3, 0, 1, 0, 0, 0};             // column -> file index (fl 0, fr 1, rl 2, rr 3)
+                put(footOf[still1], row, FPL(i,still1), FPL(i,still1+1), 0.0); put(footOf[still2], row, FPL(i,still2), FPL(i,still2+1), 0.0);
+                put(footOf[mv1], row, FPL(i,mv1) + (FPL(i+1,mv1) - FPL(i,mv1)) / 50 * j, FPL(i,mv1+1) + (FPL(i+1,mv1+1) - FPL(i,mv1+1)) / 50 * j, z);
+                put(footOf[mv2], row, FPL(i,mv2) + (FPL(i+1,mv2) - FPL(i,mv2)) / 50 * j, FPL(i,mv2+1) + (FPL(i+1,mv2+1) - FPL(i,mv2+1)) / 50 * j, z);
+            }
+        } else {
+            for (int k = 1; k <= step; ++k, ++row) {
+                const double z = -0.000032 * k * k + 0.0016 * k;
+                const int mv = (cont == 2) ? 7 : (cont == 4) ? 3 : (cont == 6) ? 5 : (cont == 8) ? 1 : 0;
+                const int cols[4] = {7, 5, 1, 3};
+                for (int ft = 0; ft < 4; ++ft) {
+                    const int cc = cols[ft];
+                    if (cc == mv) put(ft, row, FPL(i,cc) + (FPL(i+1,cc) - FPL(i,cc)) / step * k, FPL(i,cc+1) + (FPL(i+1,cc+1) - FPL(i,cc+1)) / step * k, z);
+                    else put(ft, row, FPL(i,cc), FPL(i,cc+1), 0.0);
+                }
+            }
+            cont = (cont == 8) ? 1 : cont + 1;
+        }
+    }
+    return n;
+}
+
+// fprintf(file, '%d %d %d\n', row): MATLAB prints an integer-valued double with %d and anything else with %e
+int ismpc_a_write_trajectory_txt(const char* path, const double* rows3, int n)
+{
+    if (!path || !rows3 || n < 0) return fail_a(-1, "bad argument");
+    FILE* f = std::fopen(path, "w");
+    if (!f) return fail_a(-1, std::string("cannot open ") + path);
+    for (int r = 0; r < n; ++r) {
+        for (int c = 0; c < 3; ++c) {
+            const double v = rows3[(size_t)r * 3 + c];
+            if (v == std::floor(v) && std::fabs(v) < 1e15) std::fprintf(f, "%lld", (long long)v); else std::fprintf(f, "%e", v);
+            std::fputc(c == 2 ? '\n' : ' ', f);
+        }
+    }
+    std::fclose(f);
     return 0;
 }
 

@@ -2,6 +2,7 @@
 include/ismpc_a.h: plan generators (init_quadruped*.m) and the per-tick ISMPC QP with footstep adaptation
 (quad_walk_no_plots.m / quad_as_bip_no_plots.m loop body).  All compute is HIP; nothing is solved in Python."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -32,7 +33,10 @@ OUT_A = np.dtype([("com_before", "<f8", 2), ("vel_after", "<f8", 2), ("u0", "<f8
 assert STATE_A.itemsize == 96 and OUT_A.itemsize == 80
 
 EXPORTS_A = ["ismpc_a_params_default", "ismpc_a_gait_default", "ismpc_a_plan", "ismpc_a_create", "ismpc_a_destroy",
-             "ismpc_a_initial_state", "ismpc_a_tick_batch_device", "ismpc_a_rollout_device", "ismpc_a_last_error"]
+             "ismpc_a_initial_state", "ismpc_a_tick_batch_device", "ismpc_a_rollout_device", "ismpc_a_last_error",
+             "ismpc_a_feet_rows", "ismpc_a_feet_init_device", "ismpc_a_tick_feet_batch_device",
+             "ismpc_a_rollout_feet_device", "ismpc_a_foot_trajectories", "ismpc_a_write_trajectory_txt"]
+FEET_PAD = 8
 
 _bound = False
 
@@ -51,6 +55,12 @@ def _l():
         lib.ismpc_a_tick_batch_device.argtypes = [vp, ci, vp, vp, vp, vp]; lib.ismpc_a_tick_batch_device.restype = ci
         lib.ismpc_a_rollout_device.argtypes = [vp, ci, vp, ci, vp, vp]; lib.ismpc_a_rollout_device.restype = ci
         lib.ismpc_a_last_error.argtypes = []; lib.ismpc_a_last_error.restype = C.c_char_p
+        lib.ismpc_a_feet_rows.argtypes = [vp]; lib.ismpc_a_feet_rows.restype = ci
+        lib.ismpc_a_feet_init_device.argtypes = [vp, C.POINTER(GaitA), vp, ci, ci, vp, vp]; lib.ismpc_a_feet_init_device.restype = ci
+        lib.ismpc_a_tick_feet_batch_device.argtypes = [vp, ci, vp, vp, vp, vp, vp]; lib.ismpc_a_tick_feet_batch_device.restype = ci
+        lib.ismpc_a_rollout_feet_device.argtypes = [vp, ci, vp, ci, vp, vp, vp]; lib.ismpc_a_rollout_feet_device.restype = ci
+        lib.ismpc_a_foot_trajectories.argtypes = [C.POINTER(GaitA), ci, vp, ci, ci, vp]; lib.ismpc_a_foot_trajectories.restype = ci
+        lib.ismpc_a_write_trajectory_txt.argtypes = [C.c_char_p, vp, ci]; lib.ismpc_a_write_trajectory_txt.restype = ci
         _bound = True
     return lib
 
@@ -82,6 +92,26 @@ def plan(g):
     if used < 0:
         raise IsmpcAError(_l().ismpc_a_last_error().decode())
     return fp[:used].copy(), ce
+
+
+def foot_trajectories(g, step, foot_plan, sim_duration=2000):
+    """Host: the four foot files (fl, fr, rl, rr) of one instance, [4, rows, 3]  (quad_*_no_plots.m foot writers)."""
+    fp = np.ascontiguousarray(foot_plan, dtype=np.float64)
+    n = (sim_duration // step) * step
+    dst = np.zeros((4, n, 3))
+    rc = _l().ismpc_a_foot_trajectories(C.byref(g), int(step), fp.ctypes.data_as(C.c_void_p), fp.shape[0], int(sim_duration),
+                                        dst.ctypes.data_as(C.c_void_p))
+    if rc < 0:
+        raise IsmpcAError(_l().ismpc_a_last_error().decode())
+    return dst
+
+
+def write_trajectory_txt(path, rows3):
+    """The text wire format the DART controller reads back (Controller.cpp:147-281): MATLAB's '%d %d %d\n'."""
+    a = np.ascontiguousarray(rows3, dtype=np.float64).reshape(-1, 3)
+    rc = _l().ismpc_a_write_trajectory_txt(os.fsencode(path), a.ctypes.data_as(C.c_void_p), a.shape[0])
+    if rc != 0:
+        raise IsmpcAError(_l().ismpc_a_last_error().decode())
 
 
 class GaitGenerator:
@@ -128,6 +158,29 @@ class GaitGenerator:
                                          C.c_void_p(stream) if stream else None)
         if rc != 0:
             raise IsmpcAError(_l().ismpc_a_last_error().decode())
+
+    def feet_init_torch(self, g, foot_plan, batch, device="cuda:0"):
+        """Per-instance foot plans on the device: float64 tensor [batch, rows + FEET_PAD, 8]."""
+        import torch
+        fp = np.ascontiguousarray(foot_plan, dtype=np.float64)
+        feet = torch.empty((batch, fp.shape[0] + FEET_PAD, 8), dtype=torch.float64, device=device)
+        stream = torch.cuda.current_stream(feet.device).cuda_stream
+        rc = _l().ismpc_a_feet_init_device(self._h, C.byref(g), fp.ctypes.data_as(C.c_void_p), fp.shape[0], int(batch),
+                                           C.c_void_p(feet.data_ptr()), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise IsmpcAError(_l().ismpc_a_last_error().decode())
+        return feet
+
+    def rollout_feet_torch(self, state_u8, feet, ticks):
+        import torch
+        b = state_u8.shape[0]
+        traj = torch.empty((ticks, b, 80), dtype=torch.uint8, device=state_u8.device)
+        stream = torch.cuda.current_stream(state_u8.device).cuda_stream
+        rc = _l().ismpc_a_rollout_feet_device(self._h, b, C.c_void_p(state_u8.data_ptr()), int(ticks), C.c_void_p(traj.data_ptr()),
+                                              C.c_void_p(feet.data_ptr()), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise IsmpcAError(_l().ismpc_a_last_error().decode())
+        return traj
 
     # torch conveniences
     def tick_torch(self, state_u8, push=None):

@@ -36,6 +36,10 @@ def main():
         arrs = {"com": com}
         if vel:
             arrs["vel"] = np.loadtxt(os.path.join(REF, d, vel[0]))
+        for ft in ("fl", "fr", "rl", "rr"):                       # swing-foot files
+            ff = [f for f in files if f.startswith(f"foot_{ft}_")]
+            if ff:
+                arrs[f"foot_{ft}"] = np.loadtxt(os.path.join(REF, d, ff[0]))
         np.savez_compressed(os.path.join(HERE, f"formA_matlab_{name}.npz"), **arrs)
         meta[name] = {"source": f"AMR_code_DART/MATLAB_trajectories/{d}/{traj}", "gait": gait, "phi": phi, "disp_A": dA,
                       "rows": int(com.shape[0]), "has_velocity": bool(vel)}

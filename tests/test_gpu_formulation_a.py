@@ -146,3 +146,37 @@ def test_overflow_and_bad_index_flags(FA):
     st = gen.initial_state(g.disp_C, batch=2); st["j"] = [1, 4900]; st["fc"] = [1, 99]
     out = q_from_dev(gen.tick_torch(q_to_dev(st)), FA.OUT_A)
     assert out["status"][0] == 0 and out["status"][1] == FA.ST_BAD_INDEX
+
+
+@pytest.mark.parametrize("name", ["trot_phipi4", "trot_phipi2", "walk_phipi4", "walk_phi0"])
+def test_foot_files_from_device_rollout(FA, name, tmp_path):
+    """SURVEY.md 8f2 + 8f3 end to end on the device: 2000 ticks with the swing-foot QP after every tick, the foot
+    plan read back, the four foot files generated -- against the checked-in MATLAB foot_*.txt, against the oracle,
+    and written / re-read in the text wire format the DART controller parses (Controller.cpp:147-281)."""
+    import torch
+    from oracle import oracle_a as A
+    gen, g, m = make_gen(FA, name)
+    fp0, ce = FA.plan(g)
+    ticks = 2000
+    st = q_to_dev(gen.initial_state(g.disp_C, batch=2))
+    feet = gen.feet_init_torch(g, fp0, batch=2)
+    traj = gen.rollout_feet_torch(st, feet, ticks)
+    torch.cuda.synchronize()
+    out = q_from_dev(traj, FA.OUT_A)
+    assert (out["status"] == 0).all()
+    fpl = feet.cpu().numpy()
+    assert np.array_equal(fpl[0], fpl[1])
+    files = FA.foot_trajectories(g, gen.params.step, fpl[0], ticks)
+    z = np.load(os.path.join(GOLDEN, f"formA_matlab_{name}.npz"))
+    tol = 3e-6 if m["gait"] == "trot" else 5e-5
+    for k, ft in enumerate(("fl", "fr", "rl", "rr")):
+        assert np.abs(files[k] - z[f"foot_{ft}"]).max() <= tol, (ft, np.abs(files[k] - z[f"foot_{ft}"]).max())
+    kind = A.WALK if m["gait"] == "walk" else A.TROT
+    sim = A.SimA(A.gait(kind, m["phi"], m["disp_A"]), A.params(kind), backend="gi")
+    sim.enable_feet(); sim.run(ticks)
+    assert np.abs(files - sim.foot_trajectories(ticks)).max() <= 1e-7
+    # wire format round trip: what the controller's sscanf("%f %f %f") would read
+    p = tmp_path / f"foot_fl_{name}.txt"
+    FA.write_trajectory_txt(str(p), files[0])
+    back = np.loadtxt(p)
+    assert back.shape == (ticks, 3) and np.abs(back - z["foot_fl"]).max() <= tol + 1e-6
