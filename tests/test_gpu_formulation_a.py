@@ -180,3 +180,43 @@ def test_foot_files_from_device_rollout(FA, name, tmp_path):
     FA.write_trajectory_txt(str(p), files[0])
     back = np.loadtxt(p)
     assert back.shape == (ticks, 3) and np.abs(back - z["foot_fl"]).max() <= tol + 1e-6
+
+
+@pytest.mark.parametrize("kind_name,over", [("walk", dict(C=150, P=300, F=4)),                 # BASELINE config 4 shape (RL=3, F=4)
+                                            ("walk", dict(C=200, P=400, F=5)),                 # config 5 shape, step 50 (RL=4, F=5)
+                                            ("trot", dict(C=200, P=400, F=6, step=40, ds=24)),  # config 5 shape, step 40 (RL=4, F=6)
+                                            ("walk", dict(C=60, P=120, F=3))])                 # short horizon (RL=2 with idle lanes)
+def test_other_horizons_against_oracle(FA, kind_name, over):
+    """F_A = ceil(C/step)+1 footsteps for long horizons (SURVEY.md 'Index limits'); every (rows-per-lane, F) kernel
+    instantiation that the BASELINE configs reach, nominal closed loop + pushed single ticks, against the oracle."""
+    import torch
+    from oracle import oracle_a as A
+    kind = A.WALK if kind_name == "walk" else A.TROT
+    phi, dA = np.pi / 4, 0.1
+    g = FA.default_gait(kind, phi, dA)
+    fp, ce = FA.plan(g)
+    gen = FA.GaitGenerator(FA.default_params(kind, **over), ce)
+    okw = {("C_" if k == "C" else k): v for k, v in over.items()}
+    sim = A.SimA(A.gait(kind, phi, dA), A.params(kind, **okw), backend="gi")
+    ticks = 130
+    st = q_to_dev(gen.initial_state(g.disp_C, batch=1))
+    out = q_from_dev(gen.rollout_torch(st, ticks), FA.OUT_A)[:, 0]
+    torch.cuda.synchronize()
+    ref = sim.run(ticks)
+    assert (out["status"] == 0).all() and (ref["rv"] == 0).all()
+    assert np.abs(out["com_before"] - ref["com_before"]).max() <= 1e-6 * max(1.0, np.abs(ref["com_before"]).max())
+    assert np.abs(out["u0"] - ref["u0"]).max() <= 1e-6 and np.abs(out["f0"] - ref["f0"]).max() <= 1e-7
+    # pushed ticks from the end state
+    rng = np.random.default_rng(1)
+    fin = q_from_dev(st, FA.STATE_A)
+    pushes = np.stack([rng.uniform(-0.03, 0.03, 12), rng.uniform(-0.05, 0.05, 12)], 1)
+    d_st = q_to_dev(np.repeat(fin, 12)); d_push = torch.from_numpy(pushes.copy()).to("cuda:0")
+    o2 = q_from_dev(gen.tick_torch(d_st, d_push), FA.OUT_A)
+    base = sim.state.copy(); plan = sim.get_plan()
+    for i in range(12):
+        sim.state = base; sim.set_plan(*plan)
+        r = sim.tick(tuple(pushes[i]))
+        assert r["rv"][0] == 0 and r["rv"][1] == 0
+        assert np.abs(o2["u0"][i] - r["u0"]).max() <= 1e-6 * max(1.0, np.abs(r["u0"]).max()), (i, o2["u0"][i], r["u0"])
+        assert np.abs(o2["f0"][i] - r["f0"]).max() <= 1e-7
+    assert (o2["status"] == 0).all()
