@@ -79,6 +79,17 @@ typedef struct ismpc_a_out {            /* 80 bytes */
     int32_t active;                     /* final working-set sizes: x | y << 16 */
 } ismpc_a_out;
 
+/* Per-instance gait parameters for Monte-Carlo / parameter-sweep batches (BASELINE.json configs[4]): every field
+ * overrides the handle-wide value of ismpc_a_params for one instance (32 bytes).  The .m scripts hard-code these at
+ * quad_walk_no_plots.m:20-45 / quad_as_bip_no_plots.m:16-39; a sweep re-runs the script once per value. */
+typedef struct ismpc_a_inst {
+    double  height;                     /* CoM height: eta = sqrt(grav / height), A_upd / B_upd, the stability row */
+    double  Qf;                         /* Qfootsteps */
+    int32_t step, ds;                   /* step_duration, dsSamples */
+    int32_t F;                          /* footsteps in this instance's horizon, 1 <= F <= ismpc_a_params.F of the handle */
+    int32_t plan;                       /* base plan: 0 = the one given to ismpc_a_create, k = k-th ismpc_a_add_plan */
+} ismpc_a_inst;
+
 typedef struct ismpc_a_handle ismpc_a_handle;
 
 void ismpc_a_params_default(int gait, ismpc_a_params* p);
@@ -102,6 +113,15 @@ int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state
 /* `ticks` ticks, out_traj NULL or ticks x batch records. */
 int ismpc_a_rollout_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, int ticks,
                            ismpc_a_out* out_traj_dev, void* stream);
+
+/* Per-instance gait parameters (one ismpc_a_inst per instance, device pointer).  The handle fixes C, P, dt, w, the
+ * kinematic limits and the maximum F; height, Qf, step, ds, F and the base plan come from inst_dev.  An instance
+ * whose record is invalid (ds >= step, F out of range, unknown plan, ...) gets ISMPC_A_ST_BAD_INDEX and is left alone. */
+int ismpc_a_add_plan(ismpc_a_handle* h, const double* center);      /* returns the plan index (1..3) or a negative error */
+int ismpc_a_tick_batch_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev,
+                                   const double* push_dev, ismpc_a_out* out_dev, void* stream);
+int ismpc_a_rollout_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev,
+                                int ticks, ismpc_a_out* out_traj_dev, void* stream);
 
 /* ---- swing-foot re-placement (the scripts' second quadprog) and the trajectory wire format -------------------
  *   ismpc_a_feet_init_device / ismpc_a_tick_feet_batch_device / ismpc_a_rollout_feet_device

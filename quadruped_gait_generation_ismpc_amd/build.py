@@ -36,7 +36,8 @@ def build(force=False, verbose=False):
     out = None if verbose else subprocess.DEVNULL
     if force or _stale(LIB_HIP, deps):
         subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-I", os.path.join(ROOT, "include")] + hip_src + ["-o", LIB_HIP], stdout=out)
+                               "-I", os.path.join(ROOT, "include")] + os.environ.get("ISMPC_HIPCC_FLAGS", "").split()
+                              + hip_src + ["-o", LIB_HIP], stdout=out)
     return LIB_HIP
 
 

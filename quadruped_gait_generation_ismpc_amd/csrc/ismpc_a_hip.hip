@@ -43,6 +43,7 @@ struct DevA {
     const double *fsx, *fsy;           // base plan, 0-based (fs_plan(k+1))
     const double *clx0, *cly0, *clx1, *cly1;   // centreline: initial / rebuilt structure, 0-based (cl(k+1))
     double* scratch;                   // per-workgroup S^-1 : ldq x ldq doubles each
+    const double *plan_x[4], *plan_y[4]; int nplans; double grav;   // base plans selectable per instance (ismpc_a_inst.plan)
 };
 
 // ---- wave / block primitives ------------------------------------------------------------------
@@ -613,25 +614,55 @@ template <int F> __device__ __forceinline__ double border_elem(int e, int k1, do
     return (-mr + mp) * isq;
 }
 
-// RL = ZMP rows per lane (C <= 64 RL), F = footsteps in the horizon (m = 2F+1 border columns)
-template <int RL, int F>
-__global__ __launch_bounds__(T, 4)
+// centreline value cl(k0+1) without the table: quad_walk_no_plots.m:86-99 (initial structure) / :540-549 (rebuilt one),
+// linspace as MATLAB evaluates it.  Used when step / ds differ per instance.
+__device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int step, int ds, bool rebuilt, int k0)
+{
+    const int s = k0 / step, r = k0 - s * step, q = r - (step - ds);
+    const double d1 = fs[s];
+    if (q <= 0 || (rebuilt && s == 0)) return d1;
+    const double d2 = fs[s + 1];
+    if (q == ds - 1) return d2;
+    return d1 + ((double)q * (d2 - d1)) / (double)(ds - 1);
+}
+
+// RL = ZMP rows per lane (C <= 64 RL), F = footsteps in the horizon (m = 2F+1 border columns).
+// PI: per-instance gait parameters (ismpc_a_inst): height, Qf, step, ds, F <= the template F, base plan.
+// Residency target (workgroups per CU), measured on MI355X at batch 16 384 (scripts/occ_sweep.sh): the 128-VGPR budget of
+// 4 per CU spills 80-220 registers per lane; 3 per CU is best for 2 rows per lane (walk C=100: 5.0e6 ticks/s vs 4.0e6),
+// 2 per CU for 3-4 rows per lane (walk C=150: 2.2e6 vs 1.4e6; Monte-Carlo C=200: 1.17e6 vs 0.75e6).
+#ifndef ISMPC_A_WAVE_MINBLOCKS
+#define ISMPC_A_WAVE_MINBLOCKS (RL <= 2 ? 3 : 2)
+#endif
+template <int RL, int F, bool PI>
+__global__ __launch_bounds__(T, ISMPC_A_WAVE_MINBLOCKS)
 void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
-                       const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch)
+                       const ismpc_a_inst* __restrict__ ipar, const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch,
+                       int* __restrict__ work_counter)
 {
     constexpr int m = 2 * F + 1, NK = m * (m + 1), NE = (NK + 63) / 64;
     __shared__ WaveLds<F> lds_all[T / 64];
     __shared__ double a_s[T], pa_s[T + 1];                  // stability row and its prefix sums: same for every QP of the handle
+    __shared__ double a_pi[PI ? T / 64 : 1][PI ? T : 1], pa_pi[PI ? T / 64 : 1][PI ? T + 1 : 1];   // ... or one per wavefront
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds<F>& L = lds_all[wv];
     const int C = c.C, P = c.P;
-    const double dt = c.dt, Qf = c.Qf, sq = sqrt(c.Qf), isq = 1.0 / sq, idt2 = 1.0 / (dt * dt);
+    const double dt = c.dt, idt2 = 1.0 / (dt * dt);
     const bool klane = lane >= 1 && lane <= F;            // lane r owns kinematic row r (and f_r)
-    for (int k = threadIdx.x; k <= C; k += T) { pa_s[k] = c.PA[k]; if (k < C) a_s[k] = c.a[k]; }
-    __syncthreads();
+    if (!PI) {
+        for (int k = threadIdx.x; k <= C; k += T) { pa_s[k] = c.PA[k]; if (k < C) a_s[k] = c.a[k]; }
+        __syncthreads();
+    }
+    const double* ap = PI ? a_pi[PI ? wv : 0] : a_s;
+    const double* pap = PI ? pa_pi[PI ? wv : 0] : pa_s;
 
-    for (int work = blockIdx.x * (T / 64) + wv; work < 2 * batch; work += gridDim.x * (T / 64)) {
+    // QPs are claimed one at a time from a global counter: iteration counts differ a lot between instances
+    for (;;) {
+        int claimed = 0;
+        if (lane == 0) claimed = atomicAdd(work_counter, 1);
+        const int work = __builtin_amdgcn_readfirstlane(claimed);
+        if (work >= 2 * batch) break;
         const int inst = work >> 1, axis = work & 1;
         const ismpc_a_state st = state_in[inst];
         const double pos = axis == 0 ? st.x : st.y;
@@ -640,13 +671,44 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
         const double cur = axis == 0 ? st.cur_x : st.cur_y;
         const double off = axis == 0 ? st.off_x : st.off_y;
         const int j = st.j, fc = st.fc;
-        const double* fs = axis == 0 ? c.fsx : c.fsy;
+        int status = 0;
+        // ---- gait parameters: the handle's, or this instance's
+        int step_ = c.step, ds_ = c.ds, Fi = F, plan = 0;
+        double Qf = c.Qf, eta = c.eta, aa = c.aa;
+        if (PI) {
+            const ismpc_a_inst ip = ipar[inst];
+            step_ = ip.step; ds_ = ip.ds; Fi = ip.F; plan = ip.plan; Qf = ip.Qf;
+            if (step_ < 2 || ds_ < 2 || ds_ >= step_ || Fi < 1 || Fi > F || plan < 0 || plan >= c.nplans || !(ip.height > 0) || !(Qf > 0)) {
+                status |= ISMPC_A_ST_BAD_INDEX; step_ = 2; ds_ = 1; Fi = 1; plan = 0; Qf = 1.0; eta = 1.0;
+            } else eta = sqrt(c.grav / ip.height);
+        }
+        const double sq = sqrt(Qf), isq = 1.0 / sq;
+        const double* fs = PI ? (axis == 0 ? c.plan_x[plan] : c.plan_y[plan]) : (axis == 0 ? c.fsx : c.fsy);
         const double* cl = st.rebuilt ? (axis == 0 ? c.clx1 : c.cly1) : (axis == 0 ? c.clx0 : c.cly0);
         const double cloff = st.rebuilt ? off : 0.0;
-        int status = 0;
-        if (fc < 1 || fc + F > c.n_gait || j < 1 || j + P > c.ncl || j < c.step * (fc - 1) || j > c.step * fc - 1)
+        const int ncl = PI ? (c.n_gait - 1) * step_ : c.ncl;
+        if (fc < 1 || fc + Fi > c.n_gait || j < 1 || j + P > ncl || j < step_ * (fc - 1) || j > step_ * fc - 1)
             status |= ISMPC_A_ST_BAD_INDEX;
         const double zlo0 = -(-1.0 * (-zmp - c.w / 2)), zhi0 = 1.0 * (-zmp + c.w / 2);       // band without the current-footstep term
+        if (PI) {
+            // stability row a_i (quad_walk_no_plots.m:233-238), its prefix sums and a'a for this instance's eta
+            double* aw = a_pi[PI ? wv : 0]; double* paw = pa_pi[PI ? wv : 0];
+            const double lam = exp(-eta * dt);
+            const double k1c = (1 / eta) * (1 - lam) / (1 - pow(lam, (double)C)), k2c = dt * 1.0 * exp(-eta * dt * C);
+            double av[RL], cum[RL], loc = 0.0, sqs = 0.0;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) {
+                const int i0 = lane * RL + k;
+                av[k] = (i0 < C) ? k1c * exp(-eta * dt * i0) - k2c : 0.0;
+                loc += av[k]; cum[k] = loc; sqs += av[k] * av[k];
+            }
+            const double base = wave_scan_up(loc) - loc;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) { const int i0 = lane * RL + k; if (i0 < C) { aw[i0] = av[k]; paw[i0 + 1] = base + cum[k]; } }
+            if (lane == 0) paw[0] = 0.0;
+            aa = wave_sum_d(sqs);
+            WAVE_LDS_SYNC();
+        }
 
         // ---- per-row data: lane owns ZMP rows lane*RL+1 .. lane*RL+RL (row i = sample i, u index i-1)
         double u[RL], zlo[RL], zhi[RL], w1[RL], inrm[RL], mu[RL];
@@ -657,11 +719,11 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
             const int i = lane * RL + k + 1;
             u[k] = 0.0; mu[k] = 0.0; sta[k] = 0; prv[k] = 0; nxt[k] = 0;
             if (i <= C) {
-                int pf = (j + i) / c.step - fc + 1; if (pf < 0) pf = 0;
-                const int rem = c.step * (fc + pf) - (j + i);
-                w1[k] = (rem > c.ds) ? 1.0 : (double)rem / c.ds;                  // mapping(i, pf+1); the next column gets 1 - w1
+                int pf = (j + i) / step_ - fc + 1; if (pf < 0) pf = 0;
+                const int rem = step_ * (fc + pf) - (j + i);
+                w1[k] = (rem > ds_) ? 1.0 : (double)rem / ds_;                    // mapping(i, pf+1); the next column gets 1 - w1
                 k1[k] = pf;
-                ovf = ovf || pf > F || (rem <= c.ds && pf + 1 > F);
+                ovf = ovf || pf > Fi || (rem <= ds_ && pf + 1 > Fi);
                 const double m1 = (pf == 0) ? w1[k] : 0.0;
                 zhi[k] = zhi0 + m1 * cur; zlo[k] = zlo0 + m1 * cur;
                 const double w2 = 1.0 - w1[k];
@@ -674,11 +736,19 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
         if (__builtin_amdgcn_ballot_w64(ovf) != 0) status |= ISMPC_A_ST_OVERFLOW;
         // anticipative tail (quad_walk_no_plots.m:227-231)
         double tl = 0.0;
-        if (!(status & ISMPC_A_ST_BAD_INDEX))
-            for (int i = C + 1 + lane; i <= P; i += 64) tl += c.wtail[i - (C + 1)] * ((cl[j + i - 1] + cloff) - cur);
+        if (!(status & ISMPC_A_ST_BAD_INDEX)) {
+            if (PI) {
+                const double om = 1 - exp(-eta * dt);
+                for (int i = C + 1 + lane; i <= P; i += 64)
+                    tl += exp(-eta * dt * i) * om * ((cl_closed(fs, step_, ds_, st.rebuilt != 0, j + i - 1) + cloff) - cur);
+            } else
+                for (int i = C + 1 + lane; i <= P; i += 64) tl += c.wtail[i - (C + 1)] * ((cl[j + i - 1] + cloff) - cur);
+        }
         double tail = wave_sum_d(tl);
-        if (!(status & ISMPC_A_ST_BAD_INDEX)) tail += c.wP * ((cl[P - 1] + cloff) - cur);
-        const double beq = pos + vel / c.eta - zmp - tail;
+        if (!(status & ISMPC_A_ST_BAD_INDEX))
+            tail += PI ? exp(-eta * dt * P) * ((cl_closed(fs, step_, ds_, st.rebuilt != 0, P - 1) + cloff) - cur)
+                       : c.wP * ((cl[P - 1] + cloff) - cur);
+        const double beq = pos + vel / eta - zmp - tail;
         // ---- kinematic row r and footstep f_r live in lane r (1..F); Khat_r = sqrt(Qf) (f_r - f_{r-1})
         double fr = 0.0, klo = -INFINITY, khi = INFINITY, muK = 0.0;
         int kact = 0;
@@ -690,15 +760,16 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
             if (r == 1) { bup = bup + cur; blo = blo - cur; }
             khi = bup; klo = -blo;
             fr = (status & ISMPC_A_ST_BAD_INDEX) ? 0.0 : fs[fc + r - 1] + off;
+            if (PI && r > Fi) { khi = INFINITY; klo = -INFINITY; fr = 0.0; }      // beyond this instance's horizon: no variable, no row
         }
         const double knrm = (lane >= 2) ? sq * 0.70710678118654752440 : sq;   // 1 / |K_r|_{H^-1}: |kvec_r|^2 = 2 (r >= 2) or 1
         int iters = 0, qz = 0, qk = 0;
         double muE = 0.0;
         if (status == 0) {
             // ---- equality first: u = (b / a'a) a
-            const double t0 = beq / c.aa;
+            const double t0 = beq / aa;
 #pragma unroll
-            for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; u[k] = (i <= C) ? t0 * a_s[i - 1] : 0.0; }
+            for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; u[k] = (i <= C) ? t0 * ap[i - 1] : 0.0; }
             muE = t0;
             for (int e = lane; e < m * m; e += 64) L.G[e] = 0.0;
             WAVE_LDS_SYNC();
@@ -744,7 +815,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 const int kr = row - C;                                           // kinematic index when !isZ
                 // ---- the new row: border row Vp (one element per lane), footstep part mt, norm, border products dX
                 int p_k1 = 0; double p_w1 = 1.0, p_pa = 0.0;
-                if (isZ) { p_k1 = L.k1s[row - 1]; p_w1 = L.w1s[row - 1]; p_pa = pa_s[row]; }
+                if (isZ) { p_k1 = L.k1s[row - 1]; p_w1 = L.w1s[row - 1]; p_pa = pap[row]; }
                 const double p_w2 = 1.0 - p_w1;
                 const double vp = (isZ && lane < m) ? border_elem<F>(lane, p_k1, p_w1, p_pa, dt, isq) : 0.0;
                 double mt_e = 0.0, dx_e = 0.0;                                    // lane e: mt[e] (e < F), dX[e] (e >= F)
@@ -792,8 +863,8 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                             if (sta[k] != 0 && i > row) lb = min(lb, i);
                         }
                         na = wave_max_i(la); nb = wave_min_i(lb); if (nb == (1 << 30)) nb = 0;
-                        if (na > 0 && lane < m) va = border_elem<F>(lane, L.k1s[na - 1], L.w1s[na - 1], pa_s[na], dt, isq);
-                        if (nb > 0 && lane < m) vb = border_elem<F>(lane, L.k1s[nb - 1], L.w1s[nb - 1], pa_s[nb], dt, isq);
+                        if (na > 0 && lane < m) va = border_elem<F>(lane, L.k1s[na - 1], L.w1s[na - 1], pap[na], dt, isq);
+                        if (nb > 0 && lane < m) vb = border_elem<F>(lane, L.k1s[nb - 1], L.w1s[nb - 1], pap[nb], dt, isq);
                         if (nb == 0) { vint = va; th = 0.0; }
                         else if (na == 0) { th = (double)row / (double)nb; vint = th * vb; }
                         else { th = (double)(row - na) / (double)(nb - na); vint = va + th * (vb - va); }
@@ -819,7 +890,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                             if (jj < m) {
                                 val = L.G[i * m + jj];
                                 if (i < F && jj == i) val += 1.0;
-                                if (i == F && jj == F) val -= c.aa;
+                                if (i == F && jj == F) val -= aa;
                                 if (i > F && jj > F) {
                                     const int r1 = i - F, r2 = jj - F;
                                     val -= (r1 == r2) ? (r1 >= 2 ? 2.0 : 1.0) : ((r1 - r2 == 1 || r2 - r1 == 1) ? -1.0 : 0.0);
@@ -868,7 +939,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
 #pragma unroll
                     for (int k = 0; k < RL; ++k) {
                         const int i = lane * RL + k + 1;
-                        svl[k] = (i <= C) ? (w1[k] * L.comb[k1[k]] + (1.0 - w1[k]) * L.comb[k1[k] + 1]) - dt * pa_s[i] * cE : 0.0;
+                        svl[k] = (i <= C) ? (w1[k] * L.comb[k1[k]] + (1.0 - w1[k]) * L.comb[k1[k] + 1]) - dt * pap[i] * cE : 0.0;
                         if (i <= C) L.sv[i - 1] = svl[k];
                     }
                     WAVE_LDS_SYNC();
@@ -933,7 +1004,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         const double incl = wave_scan_up(ls);
                         const double above = rl_d(incl, 63) - incl;               // lanes above this one
 #pragma unroll
-                        for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; if (i <= C) u[k] += t * ((suf[k] + above) - cE * a_s[i - 1]); }
+                        for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; if (i <= C) u[k] += t * ((suf[k] + above) - cE * ap[i - 1]); }
                         if (klane) {
                             // z_f[r] = ( n+_f[r] + sqrt(Qf) c1[r] - sqrt(Qf) (cK[r] - cK[r+1]) ) / Qf
                             const int r = lane;
@@ -979,9 +1050,9 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         const int pa_ = at_row<RL>(prv, lrow), pb_ = at_row<RL>(nxt, lrow);
                         double vl_ = 0.0, wa_ = 0.0, wb_ = 0.0;
                         if (lane < m) {
-                            vl_ = border_elem<F>(lane, L.k1s[lrow - 1], L.w1s[lrow - 1], pa_s[lrow], dt, isq);
-                            if (pa_ > 0) wa_ = border_elem<F>(lane, L.k1s[pa_ - 1], L.w1s[pa_ - 1], pa_s[pa_], dt, isq);
-                            if (pb_ > 0) wb_ = border_elem<F>(lane, L.k1s[pb_ - 1], L.w1s[pb_ - 1], pa_s[pb_], dt, isq);
+                            vl_ = border_elem<F>(lane, L.k1s[lrow - 1], L.w1s[lrow - 1], pap[lrow], dt, isq);
+                            if (pa_ > 0) wa_ = border_elem<F>(lane, L.k1s[pa_ - 1], L.w1s[pa_ - 1], pap[pa_], dt, isq);
+                            if (pb_ > 0) wb_ = border_elem<F>(lane, L.k1s[pb_ - 1], L.w1s[pb_ - 1], pap[pb_], dt, isq);
                             L.d1[lane] = vl_ - wa_; L.d2[lane] = (pb_ > 0 ? wb_ : 0.0) - vl_; L.d0[lane] = (pb_ > 0 ? wb_ : 0.0) - wa_;
                         }
                         WAVE_LDS_SYNC();
@@ -1014,11 +1085,19 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
         const double f0 = ok ? rl_d(fr, 1) : cur;
         if (lane == 0) {
             const double p0 = pos, v0 = vel, z0 = zmp;
-            const double np_ = (c.Au[0] * p0 + c.Au[1] * v0 + c.Au[2] * z0) + c.Bu[0] * u0;
-            const double nv_ = (c.Au[3] * p0 + c.Au[4] * v0 + c.Au[5] * z0) + c.Bu[1] * u0;
-            const double nz_ = (c.Au[6] * p0 + c.Au[7] * v0 + c.Au[8] * z0) + c.Bu[2] * u0;
+            double np_, nv_, nz_;
+            if (PI) {                                                            // A_upd, B_upd for this instance's eta (:67-71)
+                const double ch = cosh(eta * dt), sh = sinh(eta * dt);
+                np_ = (ch * p0 + (sh / eta) * v0 + (1 - ch) * z0) + (dt - sh / eta) * u0;
+                nv_ = ((eta * sh) * p0 + ch * v0 + (-eta * sh) * z0) + (1 - ch) * u0;
+                nz_ = (0.0 * p0 + 0.0 * v0 + 1.0 * z0) + dt * u0;
+            } else {
+                np_ = (c.Au[0] * p0 + c.Au[1] * v0 + c.Au[2] * z0) + c.Bu[0] * u0;
+                nv_ = (c.Au[3] * p0 + c.Au[4] * v0 + c.Au[5] * z0) + c.Bu[1] * u0;
+                nz_ = (c.Au[6] * p0 + c.Au[7] * v0 + c.Au[8] * z0) + c.Bu[2] * u0;
+            }
             ismpc_a_state* so = state + inst;
-            const bool stepped = ok && (j + 1 >= c.step * fc);
+            const bool stepped = ok && (j + 1 >= step_ * fc);
             if (ok) {
                 if (axis == 0) { so->x = np_; so->xd = nv_; so->xz = nz_; } else { so->y = np_; so->yd = nv_; so->yz = nz_; }
                 if (stepped) {
@@ -1170,6 +1249,8 @@ struct ismpc_a_handle {
     ismpc_a_state* prev = nullptr; int prev_cap = 0;     // copy of the state the tick reads
     FeetParams feet{}; double* feet_base = nullptr;     // swing-foot QPs (ismpc_a_feet_init_device)
     bool use_wave = true; int wave_blocks = 0;           // structured wavefront-per-QP kernel (default) vs workgroup-per-QP
+    int cus = 0, wave_occ[2] = {0, 0};                   // resident workgroups per CU of the wave kernel (handle-wide / per-instance parameters)
+    int* work_counter = nullptr;
     std::vector<void*> allocs;
     std::vector<double> fsx, fsy;
 };
@@ -1331,6 +1412,7 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     if (!rc) rc = upload_a(h, wt, &c.wtail);
     if (!rc) rc = upload_a(h, h->fsx, &c.fsx);
     if (!rc) rc = upload_a(h, h->fsy, &c.fsy);
+    if (!rc) { c.plan_x[0] = c.fsx; c.plan_y[0] = c.fsy; c.nplans = 1; c.grav = p->grav; }
     if (!rc) rc = upload_a(h, clx0, &c.clx0);
     if (!rc) rc = upload_a(h, cly0, &c.cly0);
     if (!rc) rc = upload_a(h, clx1, &c.clx1);
@@ -1340,7 +1422,9 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) rc = fail_a(-2, "hipGetDeviceProperties failed");
         else {
             h->slots = prop.multiProcessorCount * (c.sinv_in_lds ? 1 : 4);   // persistent grid: workgroups per CU
-            h->wave_blocks = prop.multiProcessorCount * 4;
+            h->wave_blocks = prop.multiProcessorCount * 4; h->cus = prop.multiProcessorCount;
+            if (hipMalloc((void**)&h->work_counter, sizeof(int)) != hipSuccess) rc = fail_a(-3, "counter allocation failed");
+            else h->allocs.push_back(h->work_counter);
             if (const char* e = std::getenv("ISMPC_A_KERNEL")) h->use_wave = std::strcmp(e, "block") != 0;
             void* sc = nullptr;
             if (hipMalloc(&sc, (size_t)h->slots * c.ldq * c.ldq * sizeof(double)) != hipSuccess) rc = fail_a(-3, "scratch allocation failed");
@@ -1376,8 +1460,23 @@ int ismpc_a_initial_state(const ismpc_a_handle* h, double disp_C, ismpc_a_state*
     return 0;
 }
 
-int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const double* push_dev,
-                              ismpc_a_out* out_dev, void* stream)
+int ismpc_a_add_plan(ismpc_a_handle* h, const double* center)
+{
+    if (!h || !center) return fail_a(-1, "null argument");
+    if (h->c.nplans >= 4) return fail_a(-1, "at most 4 base plans per handle");
+    HIP_TRY_A(hipSetDevice(h->device));
+    std::vector<double> px(h->p.n_gait), py(h->p.n_gait);
+    for (int i = 0; i < h->p.n_gait; ++i) { px[i] = center[i * 2]; py[i] = center[i * 2 + 1]; }
+    const int k = h->c.nplans;
+    int rc = upload_a(h, px, &h->c.plan_x[k]);
+    if (!rc) rc = upload_a(h, py, &h->c.plan_y[k]);
+    if (rc) return rc;
+    h->c.nplans = k + 1;
+    return k;
+}
+
+static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev, const double* push_dev,
+                       ismpc_a_out* out_dev, void* stream)
 {
     if (!h || batch < 0 || (batch > 0 && !state_dev)) return fail_a(-1, "bad argument");
     if (batch == 0) return 0;
@@ -1391,23 +1490,56 @@ int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state
     }
     HIP_TRY_A(hipMemcpyAsync(h->prev, state_dev, sizeof(ismpc_a_state) * (size_t)batch, hipMemcpyDeviceToDevice, s));
     if (out_dev) hipLaunchKernelGGL(ismpc_a_clear_out, dim3((batch + 255) / 256), dim3(256), 0, s, out_dev, batch);
-    if (h->use_wave) {
+    if (h->use_wave || inst_dev) {
         // structured solver, one wavefront per QP, 4 per workgroup; persistent grid
         const int rl = (h->c.C + 63) / 64;
-        const int grid = std::min((2 * batch + 3) / 4, h->wave_blocks);
         const ismpc_a_state* prev = h->prev;
-#define ISMPC_A_W(RL_, F_) hipLaunchKernelGGL((ismpc_a_tick_wave<RL_, F_>), dim3(grid), dim3(T), 0, s, h->c, prev, state_dev, push_dev, out_dev, batch)
+        const int pi = inst_dev ? 1 : 0;
+        HIP_TRY_A(hipMemsetAsync(h->work_counter, 0, sizeof(int), s));
+        // persistent grid = exactly the workgroups that are resident at once (registers / LDS decide how many per CU)
+#define ISMPC_A_W1(K_) do { if (h->wave_occ[pi] == 0) { int nb = 0; \
+                                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_, T, 0) != hipSuccess || nb < 1) nb = 1; \
+                                h->wave_occ[pi] = nb; } \
+                            const int grid = std::min((2 * batch + 3) / 4, h->cus * h->wave_occ[pi]); \
+                            hipLaunchKernelGGL(K_, dim3(grid), dim3(T), 0, s, h->c, prev, state_dev, inst_dev, push_dev, out_dev, batch, h->work_counter); } while (0)
+#define ISMPC_A_W(RL_, F_) do { if (inst_dev) ISMPC_A_W1((ismpc_a_tick_wave<RL_, F_, true>)); else ISMPC_A_W1((ismpc_a_tick_wave<RL_, F_, false>)); } while (0)
 #define ISMPC_A_WF(RL_) do { switch (h->c.F) { case 3: ISMPC_A_W(RL_, 3); break; case 4: ISMPC_A_W(RL_, 4); break; \
                                                case 5: ISMPC_A_W(RL_, 5); break; case 6: ISMPC_A_W(RL_, 6); break; default: launched = false; } } while (0)
         bool launched = true;
         switch (rl) { case 1: case 2: ISMPC_A_WF(2); break; case 3: ISMPC_A_WF(3); break; case 4: ISMPC_A_WF(4); break; default: launched = false; }
 #undef ISMPC_A_WF
 #undef ISMPC_A_W
+#undef ISMPC_A_W1
         if (launched) { HIP_TRY_A(hipGetLastError()); return 0; }
+        if (inst_dev) return fail_a(-1, "per-instance gait parameters need the structured kernel: 3 <= F <= 6 and C <= 256");
     }
     const int grid = std::min(2 * batch, h->slots);
     hipLaunchKernelGGL(ismpc_a_tick_kernel, dim3(grid), dim3(T), h->c.sinv_in_lds ? (size_t)h->c.ldq * h->c.ldq * sizeof(double) : 0, s, h->c, (const ismpc_a_state*)h->prev, state_dev, push_dev, out_dev, batch);
     HIP_TRY_A(hipGetLastError());
+    return 0;
+}
+
+int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const double* push_dev,
+                              ismpc_a_out* out_dev, void* stream)
+{
+    return tick_launch(h, batch, state_dev, nullptr, push_dev, out_dev, stream);
+}
+
+int ismpc_a_tick_batch_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev,
+                                   const double* push_dev, ismpc_a_out* out_dev, void* stream)
+{
+    if (batch > 0 && !inst_dev) return fail_a(-1, "null per-instance parameter array");
+    return tick_launch(h, batch, state_dev, inst_dev, push_dev, out_dev, stream);
+}
+
+int ismpc_a_rollout_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev, int ticks,
+                                ismpc_a_out* out_traj_dev, void* stream)
+{
+    if (!h || batch < 0 || ticks < 0) return fail_a(-1, "bad argument");
+    for (int t = 0; t < ticks; ++t) {
+        int rc = ismpc_a_tick_batch_inst_device(h, batch, state_dev, inst_dev, nullptr, out_traj_dev ? out_traj_dev + (size_t)t * batch : nullptr, stream);
+        if (rc) return rc;
+    }
     return 0;
 }
 

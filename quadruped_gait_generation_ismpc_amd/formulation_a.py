@@ -30,12 +30,14 @@ STATE_A = np.dtype([("x", "<f8"), ("xd", "<f8"), ("xz", "<f8"), ("y", "<f8"), ("
                     ("fc", "<i4"), ("j", "<i4"), ("rebuilt", "<i4"), ("reserved", "<i4")], align=False)
 OUT_A = np.dtype([("com_before", "<f8", 2), ("vel_after", "<f8", 2), ("u0", "<f8", 2), ("f0", "<f8", 2),
                   ("status", "<i4"), ("iters_x", "<i4"), ("iters_y", "<i4"), ("active", "<i4")], align=False)
-assert STATE_A.itemsize == 96 and OUT_A.itemsize == 80
+INST_A = np.dtype([("height", "<f8"), ("Qf", "<f8"), ("step", "<i4"), ("ds", "<i4"), ("F", "<i4"), ("plan", "<i4")], align=False)
+assert STATE_A.itemsize == 96 and OUT_A.itemsize == 80 and INST_A.itemsize == 32
 
 EXPORTS_A = ["ismpc_a_params_default", "ismpc_a_gait_default", "ismpc_a_plan", "ismpc_a_create", "ismpc_a_destroy",
              "ismpc_a_initial_state", "ismpc_a_tick_batch_device", "ismpc_a_rollout_device", "ismpc_a_last_error",
              "ismpc_a_feet_rows", "ismpc_a_feet_init_device", "ismpc_a_tick_feet_batch_device",
-             "ismpc_a_rollout_feet_device", "ismpc_a_foot_trajectories", "ismpc_a_write_trajectory_txt"]
+             "ismpc_a_rollout_feet_device", "ismpc_a_foot_trajectories", "ismpc_a_write_trajectory_txt",
+             "ismpc_a_add_plan", "ismpc_a_tick_batch_inst_device", "ismpc_a_rollout_inst_device"]
 FEET_PAD = 8
 
 _bound = False
@@ -61,6 +63,9 @@ def _l():
         lib.ismpc_a_rollout_feet_device.argtypes = [vp, ci, vp, ci, vp, vp, vp]; lib.ismpc_a_rollout_feet_device.restype = ci
         lib.ismpc_a_foot_trajectories.argtypes = [C.POINTER(GaitA), ci, vp, ci, ci, vp]; lib.ismpc_a_foot_trajectories.restype = ci
         lib.ismpc_a_write_trajectory_txt.argtypes = [C.c_char_p, vp, ci]; lib.ismpc_a_write_trajectory_txt.restype = ci
+        lib.ismpc_a_add_plan.argtypes = [vp, vp]; lib.ismpc_a_add_plan.restype = ci
+        lib.ismpc_a_tick_batch_inst_device.argtypes = [vp, ci, vp, vp, vp, vp, vp]; lib.ismpc_a_tick_batch_inst_device.restype = ci
+        lib.ismpc_a_rollout_inst_device.argtypes = [vp, ci, vp, vp, ci, vp, vp]; lib.ismpc_a_rollout_inst_device.restype = ci
         _bound = True
     return lib
 
@@ -178,6 +183,42 @@ class GaitGenerator:
         stream = torch.cuda.current_stream(state_u8.device).cuda_stream
         rc = _l().ismpc_a_rollout_feet_device(self._h, b, C.c_void_p(state_u8.data_ptr()), int(ticks), C.c_void_p(traj.data_ptr()),
                                               C.c_void_p(feet.data_ptr()), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise IsmpcAError(_l().ismpc_a_last_error().decode())
+        return traj
+
+    # per-instance gait parameters (INST_A records): Monte-Carlo / sweep batches
+    def add_plan(self, center):
+        ce = np.ascontiguousarray(center, dtype=np.float64)
+        if ce.shape != self.center.shape:
+            raise ValueError("plan shape differs from the handle's")
+        k = _l().ismpc_a_add_plan(self._h, ce.ctypes.data_as(C.c_void_p))
+        if k < 0:
+            raise IsmpcAError(_l().ismpc_a_last_error().decode())
+        return k
+
+    def tick_inst_torch(self, state_u8, inst_u8, push=None):
+        import torch
+        b = state_u8.shape[0]
+        assert state_u8.is_cuda and state_u8.dtype == torch.uint8 and state_u8.shape[1] == 96 and state_u8.is_contiguous()
+        assert inst_u8.is_cuda and inst_u8.dtype == torch.uint8 and inst_u8.shape == (b, 32) and inst_u8.is_contiguous()
+        out = torch.empty((b, 80), dtype=torch.uint8, device=state_u8.device)
+        stream = torch.cuda.current_stream(state_u8.device).cuda_stream
+        rc = _l().ismpc_a_tick_batch_inst_device(self._h, b, C.c_void_p(state_u8.data_ptr()), C.c_void_p(inst_u8.data_ptr()),
+                                                 C.c_void_p(push.data_ptr()) if push is not None else None,
+                                                 C.c_void_p(out.data_ptr()), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise IsmpcAError(_l().ismpc_a_last_error().decode())
+        return out
+
+    def rollout_inst_torch(self, state_u8, inst_u8, ticks):
+        import torch
+        b = state_u8.shape[0]
+        assert inst_u8.is_cuda and inst_u8.dtype == torch.uint8 and inst_u8.shape == (b, 32) and inst_u8.is_contiguous()
+        traj = torch.empty((ticks, b, 80), dtype=torch.uint8, device=state_u8.device)
+        stream = torch.cuda.current_stream(state_u8.device).cuda_stream
+        rc = _l().ismpc_a_rollout_inst_device(self._h, b, C.c_void_p(state_u8.data_ptr()), C.c_void_p(inst_u8.data_ptr()), int(ticks),
+                                              C.c_void_p(traj.data_ptr()), C.c_void_p(stream) if stream else None)
         if rc != 0:
             raise IsmpcAError(_l().ismpc_a_last_error().decode())
         return traj

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Formulation A throughput (BASELINE configs 4-5 family): one tick over a batch of perturbed nominal
 instances.  Not the headline bench (bench.py); numbers go to DESIGN.md.
-usage: python scripts/bench_a.py [walk_C150|walk_C100|trot_C160] [batch] [steps] [--cpu]"""
+usage: python scripts/bench_a.py [walk_C150|walk_C100|trot_C160|mc_C200] [batch] [steps] [--cpu]
+mc_C200 = BASELINE configs[4]: trot / walk by instance parity, per-instance CoM height, step timing and footstep count."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +14,33 @@ from quadruped_gait_generation_ismpc_amd import formulation_a as FA
 name = sys.argv[1] if len(sys.argv) > 1 else "walk_C150"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+if name == "mc_C200":
+    rng = np.random.Generator(np.random.Philox(key=20261003))
+    Cn, Pn = 200, 400
+    inst = np.zeros(batch, dtype=FA.INST_A)
+    step = rng.integers(40, 101, batch)
+    trot = (np.arange(batch) % 2) == 0
+    inst["height"] = rng.uniform(0.50, 0.62, batch); inst["Qf"] = np.where(trot, 1e7, 1e9); inst["step"] = step
+    inst["ds"] = np.round(0.6 * step).astype(np.int32); inst["F"] = -(-Cn // step) + 1; inst["plan"] = np.where(trot, 0, 1)
+    plans = [FA.plan(FA.default_gait(k, np.pi / 4, 0.1))[1] for k in (0, 1)]
+    gen = FA.GaitGenerator(FA.default_params(0, C=Cn, P=Pn, F=6), plans[0]); gen.add_plan(plans[1])
+    d_inst = q.to_device(inst)
+    d0 = q.to_device(gen.initial_state(0.88, batch=batch))
+    gen.rollout_inst_torch(d0, d_inst, 60)                                   # nominal closed loop to spread the gait phases
+    push = np.stack([rng.uniform(-0.03, 0.03, batch), rng.uniform(-0.05, 0.05, batch)], 1)
+    dpush = torch.from_numpy(push.copy()).cuda(); d = d0.clone()
+    out = gen.tick_inst_torch(d, d_inst, dpush); torch.cuda.synchronize()
+    o = q.from_device(out, FA.OUT_A)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for _ in range(steps):
+        d.copy_(d0); out = gen.tick_inst_torch(d, d_inst, dpush)
+    e1.record(); torch.cuda.synchronize(); el = time.perf_counter() - t0
+    print(json.dumps({"workload": name, "batch": batch, "steps": steps, "ticks_per_s": batch * steps / el, "ms_per_step": 1e3 * el / steps,
+                      "event_ms_per_step": e0.elapsed_time(e1) / steps, "status_nonzero": int((o["status"] != 0).sum()),
+                      "iters_mean": float((o["iters_x"] + o["iters_y"]).mean() / 2), "iters_max": int(max(o["iters_x"].max(), o["iters_y"].max())),
+                      "active_mean": float(((o["active"] & 0xffff) + (o["active"] >> 16)).mean() / 2)}))
+    sys.exit(0)
 z = np.load(os.path.join(ROOT, "tests", "golden", f"prerollA_{name}.npz"))
 tab = z["state"].view(FA.STATE_A).reshape(-1)
 kind = int(z["gait"]); g = FA.default_gait(kind, float(z["phi"]), float(z["disp_A"]))

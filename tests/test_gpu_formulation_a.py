@@ -220,3 +220,78 @@ def test_other_horizons_against_oracle(FA, kind_name, over):
         assert np.abs(o2["u0"][i] - r["u0"]).max() <= 1e-6 * max(1.0, np.abs(r["u0"]).max()), (i, o2["u0"][i], r["u0"])
         assert np.abs(o2["f0"][i] - r["f0"]).max() <= 1e-7
     assert (o2["status"] == 0).all()
+
+
+def _mc_instances(FA, A, n, seed=5, C_=200):
+    """BASELINE configs[4] draw: trot / walk by instance parity, height ~ U(0.50, 0.62), step ~ U{40..100},
+    ds = round(0.6 step), F = ceil(C / step) + 1."""
+    rng = np.random.default_rng(seed)
+    inst = np.zeros(n, dtype=FA.INST_A)
+    for i in range(n):
+        kind = A.TROT if i % 2 == 0 else A.WALK
+        step = int(rng.integers(40, 101))
+        inst[i] = (rng.uniform(0.50, 0.62), 1e7 if kind == A.TROT else 1e9, step, int(round(0.6 * step)), -(-C_ // step) + 1, 0 if kind == A.TROT else 1)
+    return inst
+
+
+def test_per_instance_parameters_against_oracle(FA):
+    """Monte-Carlo batch (BASELINE configs[4]): every instance has its own CoM height, step timing, footstep count, Qf and
+    gait; one launch on the device against one oracle run per instance (closed loop, then one pushed tick each)."""
+    import torch
+    from oracle import oracle_a as A
+    Cn, Pn, n, ticks = 200, 400, 10, 110
+    phi, dA = np.pi / 4, 0.1
+    inst = _mc_instances(FA, A, n)
+    assert inst["F"].max() <= 6 and inst["F"].min() >= 3
+    plans = [FA.plan(FA.default_gait(k, phi, dA))[1] for k in (A.TROT, A.WALK)]
+    gen = FA.GaitGenerator(FA.default_params(A.TROT, C=Cn, P=Pn, F=6), plans[0])
+    assert gen.add_plan(plans[1]) == 1
+    d_inst = q_to_dev(inst)
+    st = q_to_dev(gen.initial_state(0.88, batch=n))
+    out = q_from_dev(gen.rollout_inst_torch(st, d_inst, ticks), FA.OUT_A)
+    torch.cuda.synchronize()
+    fin = q_from_dev(st, FA.STATE_A)
+    rng = np.random.default_rng(2)
+    pushes = np.stack([rng.uniform(-0.03, 0.03, n), rng.uniform(-0.05, 0.05, n)], 1)
+    o2 = q_from_dev(gen.tick_inst_torch(st, d_inst, torch.from_numpy(pushes.copy()).to("cuda:0")), FA.OUT_A)
+    assert (out["status"] == 0).all() and (o2["status"] == 0).all()
+    for i in range(n):
+        kind = A.TROT if inst["plan"][i] == 0 else A.WALK
+        p = A.params(kind, C_=Cn, P=Pn, F=int(inst["F"][i]), step=int(inst["step"][i]), ds=int(inst["ds"][i]), Qf=float(inst["Qf"][i]))
+        p.height = float(inst["height"][i])
+        sim = A.SimA(A.gait(kind, phi, dA), p, backend="gi")
+        ref = sim.run(ticks)
+        assert (ref["rv"] == 0).all()
+        o = out[:, i]
+        assert np.abs(o["com_before"] - ref["com_before"]).max() <= 1e-6 * max(1.0, np.abs(ref["com_before"]).max()), i
+        assert np.abs(o["vel_after"] - ref["vel_after"]).max() <= 1e-6, i
+        assert np.abs(o["u0"] - ref["u0"]).max() <= 1e-6 and np.abs(o["f0"] - ref["f0"]).max() <= 1e-7, i
+        s_end = sim.state
+        assert int(s_end["fc"]) == int(fin["fc"][i]) and int(s_end["j"]) == int(fin["j"][i])        # counters bit-exact
+        r = sim.tick(tuple(pushes[i]))
+        assert r["rv"][0] == 0 and r["rv"][1] == 0
+        assert np.abs(o2["u0"][i] - r["u0"]).max() <= 1e-6 * max(1.0, np.abs(r["u0"]).max()), (i, o2["u0"][i], r["u0"])
+        assert np.abs(o2["f0"][i] - r["f0"]).max() <= 1e-7, i
+
+
+def test_per_instance_invalid_records_are_flagged(FA):
+    import torch
+    from oracle import oracle_a as A
+    g = FA.default_gait(A.WALK, 0.0, 0.1)
+    _, ce = FA.plan(g)
+    gen = FA.GaitGenerator(FA.default_params(A.WALK), ce)
+    inst = np.zeros(4, dtype=FA.INST_A)
+    inst[0] = (0.56, 1e9, 50, 30, 3, 0)          # the handle's own values
+    inst[1] = (0.56, 1e9, 50, 50, 3, 0)          # ds >= step
+    inst[2] = (0.56, 1e9, 50, 30, 4, 0)          # F beyond the handle's
+    inst[3] = (0.56, 1e9, 50, 30, 3, 1)          # plan that was never added
+    st0 = gen.initial_state(g.disp_C, batch=4)
+    st = q_to_dev(st0)
+    o = q_from_dev(gen.tick_inst_torch(st, q_to_dev(inst)), FA.OUT_A)
+    after = q_from_dev(st, FA.STATE_A)
+    assert o["status"][0] == 0 and after["j"][0] == 2
+    assert (o["status"][1:] & FA.ST_BAD_INDEX).all()
+    assert (after["j"][1:] == 1).all() and (after["x"][1:] == st0["x"][1:]).all()
+    # record 0 equals the handle-wide path bit for bit in its counters and to rounding in the solution
+    st_b = q_to_dev(st0[:1]); ob = q_from_dev(gen.tick_torch(st_b), FA.OUT_A)
+    assert np.abs(ob["u0"][0] - o["u0"][0]).max() <= 1e-9 and np.abs(ob["f0"][0] - o["f0"][0]).max() <= 1e-10
