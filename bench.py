@@ -149,6 +149,22 @@ def main():
     else:
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
+    # BASELINE configs[1] (1 024 instances on one GPU) beside the headline shard: same kernels, same inputs (first 1 024)
+    small = None
+    if world == 1 and B > 1024:
+        d_in_s, d_out_s = d_in[:1024].contiguous(), torch.empty((1024, 80), dtype=torch.uint8, device=dev)
+        for _ in range(args.warmup):
+            solver.solve_batch_torch(d_in_s, d_out_s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); ts = time.perf_counter(); e0.record()
+        for _ in range(args.steps):
+            solver.solve_batch_torch(d_in_s, d_out_s)
+        e1.record(); torch.cuda.synchronize(); el_s = time.perf_counter() - ts
+        k_ms = e0.elapsed_time(e1) / args.steps
+        small = {"workload": "BASELINE configs[1]: 1 024 instances, N=%d, one GPU" % N, "value": 1024 * args.steps / el_s, "unit": "ticks/s",
+                 "ms_per_step": 1e3 * el_s / args.steps, "kernel_ms": k_ms,
+                 "roofline_frac": algorithmic_flops_per_tick(N) * 1024 / (k_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS}
+
     out = q.from_device(d_out, q.TICK_OUT)
     if world > 1:
         allout = q.from_device(d_all, q.TICK_OUT)
@@ -183,6 +199,8 @@ def main():
                                  "traffic = HBM bytes/launch from rocprofv3 PMC (profiles/r01/pmc_affine_b8192.json), "
                                  "measured at 8192 instances/launch and scaled linearly to this batch"},
         }
+        if small is not None:
+            line["other_configs"] = [small]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, tick_in, args.cpu_budget)
         print(json.dumps(line), flush=True)

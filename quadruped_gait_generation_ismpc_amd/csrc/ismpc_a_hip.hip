@@ -585,6 +585,16 @@ __device__ __forceinline__ double rl_d(double v, int l)
 }
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
 
+// 1/x to rounding error: v_rcp_f64 + two Newton steps (the IEEE division sequence is more than twice as long, and the
+// active-set loop divides by gaps and pivots on its critical path)
+__device__ __forceinline__ double frcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // value held by the owner of ZMP row `row` (1-based, wave-uniform) in a per-row register array
 template <int RL> __device__ __forceinline__ double at_row(const double (&v)[RL], int row)
 {
@@ -625,6 +635,16 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
     if (q == ds - 1) return d2;
     return d1 + ((double)q * (d2 - d1)) / (double)(ds - 1);
 }
+
+// -DISMPC_A_PROF: per-phase shader-clock totals of the Goldfarb-Idnani loop (development aid, scripts/prof_a.py)
+#ifdef ISMPC_A_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_T0() unsigned long long pt_ = __builtin_readcyclecounter()
+#define PROF(k_) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (lane == 0 && (work & 127) == 0) { atomicAdd(&g_prof[k_], n_ - pt_); atomicAdd(&g_prof[8 + (k_)], 1ull); } pt_ = __builtin_readcyclecounter(); } while (0)
+#else
+#define PROF_T0() do {} while (0)
+#define PROF(k_) do {} while (0)
+#endif
 
 // RL = ZMP rows per lane (C <= 64 RL), F = footsteps in the horizon (m = 2F+1 border columns).
 // PI: per-instance gait parameters (ismpc_a_inst): height, Qf, step, ds, F <= the template F, base plan.
@@ -775,6 +795,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
             WAVE_LDS_SYNC();
 
             for (;;) {
+                PROF_T0();
                 // ================= most violated inactive row =================
                 if (lane <= F + 1) L.fl[lane] = fr;
                 WAVE_LDS_SYNC();
@@ -828,6 +849,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 const double npn = isZ ? (dt * dt * (double)row + ((p_k1 >= 1 ? p_w1 * p_w1 : 0.0) + p_w2 * p_w2) / Qf) : (kr >= 2 ? 2.0 : 1.0);
                 double mu_p = 0.0;
                 bool failed = false, fresh = true;                                // fresh: sviol still valid from the search
+                PROF(0);
                 // ================= steps until the row enters (Goldfarb-Idnani) =================
                 for (;;) {
                     if (++iters > c.max_iter) { status |= ISMPC_A_ST_ITER_LIMIT; failed = true; break; }
@@ -855,19 +877,12 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                     // ---- neighbours (na < row < nb) of a new ZMP row among the active ones; V there
                     int na = 0, nb = 0; double th = 0.0, va = 0.0, vb = 0.0, vint = 0.0;
                     if (isZ && qz > 0) {
-                        int la = 0, lb = 1 << 30;
-#pragma unroll
-                        for (int k = 0; k < RL; ++k) {
-                            const int i = lane * RL + k + 1;
-                            if (sta[k] != 0 && i < row) la = max(la, i);
-                            if (sta[k] != 0 && i > row) lb = min(lb, i);
-                        }
-                        na = wave_max_i(la); nb = wave_min_i(lb); if (nb == (1 << 30)) nb = 0;
+                        na = at_row<RL>(prv, row); nb = at_row<RL>(nxt, row);      // prv / nxt are kept for every row, active or not
                         if (na > 0 && lane < m) va = border_elem<F>(lane, L.k1s[na - 1], L.w1s[na - 1], pap[na], dt, isq);
                         if (nb > 0 && lane < m) vb = border_elem<F>(lane, L.k1s[nb - 1], L.w1s[nb - 1], pap[nb], dt, isq);
                         if (nb == 0) { vint = va; th = 0.0; }
-                        else if (na == 0) { th = (double)row / (double)nb; vint = th * vb; }
-                        else { th = (double)(row - na) / (double)(nb - na); vint = va + th * (vb - va); }
+                        else if (na == 0) { th = (double)row * frcp((double)nb); vint = th * vb; }
+                        else { th = (double)(row - na) * frcp((double)(nb - na)); vint = va + th * (vb - va); }
                     }
                     // ---- small quasi-definite system  [[I+G11, G1x],[Gx1, Gxx - Sxx]] cc = [h1 ; hx - dX]
                     // unknown order: 0..F-1 footstep columns, F = stability row, F+1..2F = Khat_1..F (inactive: pinned to 0)
@@ -878,6 +893,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         L.hx[lane] = h_e - dx_e;
                     }
                     WAVE_LDS_SYNC();
+                    PROF(1);
                     const unsigned long long kmask = __builtin_amdgcn_ballot_w64(klane && kact != 0);   // bit r: Khat_r active
 #pragma unroll
                     for (int s_ = 0; s_ < NE; ++s_) {
@@ -901,12 +917,13 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         }
                     }
                     WAVE_LDS_SYNC();
+                    PROF(2);
                     int cur_buf = 0;
 #pragma nounroll
                     for (int kk = 0; kk < m; ++kk) {                              // Gauss-Jordan, no pivoting (quasi-definite)
                         if (kk > F && !((kmask >> (kk - F)) & 1ull)) continue;    // pinned unknown: its column is already e_kk
                         const double* Ks = L.K[cur_buf]; double* Kd = L.K[cur_buf ^ 1];
-                        const double ipv = 1.0 / Ks[kk * (m + 1) + kk];
+                        const double ipv = frcp(Ks[kk * (m + 1) + kk]);
 #pragma unroll
                         for (int s_ = 0; s_ < NE; ++s_) {
                             const int e = lane + 64 * s_;
@@ -919,10 +936,11 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         WAVE_LDS_SYNC();
                     }
                     const double* Kf = L.K[cur_buf];
-                    const double cc_e = (lane < m) ? Kf[lane * (m + 1) + m] / Kf[lane * (m + 1) + lane] : 0.0;   // lane e: cc[e]
+                    const double cc_e = (lane < m) ? Kf[lane * (m + 1) + m] * frcp(Kf[lane * (m + 1) + lane]) : 0.0;   // lane e: cc[e]
                     if (lane < m) L.cc[lane] = cc_e;
                     WAVE_LDS_SYNC();
                     const double cE = L.cc[F];
+                    PROF(3);
                     // ---- y = coefficients on the V columns (delta_Z - V cc = sg dt^2 k_i + V y); rows see the footstep
                     // columns through comb[k1], comb[k1+1]:  comb[r] = (yM_r - yK_r + yK_{r+1}) / sqrt(Qf)
                     if (lane <= F + 1) {
@@ -943,6 +961,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         if (i <= C) L.sv[i - 1] = svl[k];
                     }
                     WAVE_LDS_SYNC();
+                    PROF(4);
                     // ---- rho per active ZMP row (tridiagonal K^-1) + interpolation weights; d.r ; dual step length
                     double rho[RL], ddl = 0.0, tcand = INFINITY; int tcode = 0;
 #pragma unroll
@@ -951,8 +970,8 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         rho[k] = 0.0;
                         if (i <= C && sta[k] != 0) {
                             const double sp = prv[k] > 0 ? L.sv[prv[k] - 1] : 0.0;
-                            double r_ = (svl[k] - sp) / (double)(i - prv[k]);
-                            if (nxt[k] > 0) r_ -= (L.sv[nxt[k] - 1] - svl[k]) / (double)(nxt[k] - i);
+                            double r_ = (svl[k] - sp) * frcp((double)(i - prv[k]));
+                            if (nxt[k] > 0) r_ -= (L.sv[nxt[k] - 1] - svl[k]) * frcp((double)(nxt[k] - i));
                             r_ *= idt2;
                             if (isZ) {
                                 if (i == na) r_ += (nb == 0) ? sg : sg * (1.0 - th);
@@ -976,14 +995,14 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                             }
                             ddl += dj * r_;
                             const double rs = (sta[k] > 0 ? 1.0 : -1.0) * r_;
-                            if (rs > 0.0) { const double tt = mu[k] / rs; if (tt < tcand) { tcand = tt; tcode = i; } }
+                            if (rs > 0.0) { const double tt = mu[k] * frcp(rs); if (tt < tcand) { tcand = tt; tcode = i; } }
                         }
                     }
                     if (lane >= F && lane < m) ddl += dx_e * cc_e;                 // border part of d.r
                     const double cK = (klane) ? L.cc[F + lane] : 0.0;              // lane r: unsigned cc of Khat_r
                     if (klane && kact != 0) {
                         const double rs = (kact > 0 ? 1.0 : -1.0) * cK;
-                        if (rs > 0.0) { const double tt = muK / rs; if (tt < tcand) { tcand = tt; tcode = C + lane; } }
+                        if (rs > 0.0) { const double tt = muK * frcp(rs); if (tt < tcand) { tcand = tt; tcode = C + lane; } }
                     }
                     const double gamma = npn - wave_sum_d(ddl);
                     const double t1 = wave_min_d(tcand);
@@ -992,6 +1011,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                     const double t2 = (gamma > 1e-12 * npn) ? -sviol / gamma : INFINITY;
                     const double t = fmin(t1, t2);
                     if (!(t < INFINITY)) { status |= (axis == 0 ? ISMPC_A_ST_X_INFEASIBLE : ISMPC_A_ST_Y_INFEASIBLE); failed = true; break; }
+                    PROF(5);
                     // ---- primal step: z_u = suffix sum of (-dt rho, + sg dt at the new row) - r_E a ; z_f from cc
                     if (t2 < INFINITY) {
                         double ls = 0.0, suf[RL];
@@ -1020,12 +1040,13 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                     if (klane && kact != 0) muK -= t * (kact > 0 ? 1.0 : -1.0) * cK;
                     muE -= t * cE;
                     mu_p += t;
+                    PROF(6);
                     if (t2 < INFINITY && t == t2) {
                         // ============ the row enters ============
                         if (isZ) {
                             if (lane < m) { L.d1[lane] = vp - va; L.d2[lane] = (nb > 0 ? vb : 0.0) - vp; L.d0[lane] = (nb > 0 ? vb : 0.0) - va; }
                             WAVE_LDS_SYNC();
-                            const double g1 = idt2 / (double)(row - na), g2 = nb > 0 ? idt2 / (double)(nb - row) : 0.0, g0 = nb > 0 ? idt2 / (double)(nb - na) : 0.0;
+                            const double g1 = idt2 * frcp((double)(row - na)), g2 = nb > 0 ? idt2 * frcp((double)(nb - row)) : 0.0, g0 = nb > 0 ? idt2 * frcp((double)(nb - na)) : 0.0;
                             for (int e = lane; e < m * m; e += 64) {
                                 const int i = e / m, jj = e - i * m;
                                 L.G[e] += g1 * L.d1[i] * L.d1[jj] + g2 * L.d2[i] * L.d2[jj] - g0 * L.d0[i] * L.d0[jj];
@@ -1034,15 +1055,16 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
 #pragma unroll
                             for (int k = 0; k < RL; ++k) {
                                 const int i = lane * RL + k + 1;
-                                if (i == row) { sta[k] = sg > 0.0 ? 1 : -1; mu[k] = mu_p; prv[k] = na; nxt[k] = nb; }
-                                if (i == na) nxt[k] = row;
-                                if (i == nb) prv[k] = row;
+                                if (i == row) { sta[k] = sg > 0.0 ? 1 : -1; mu[k] = mu_p; }
+                                if (i >= na && i < row) nxt[k] = row;              // rows that now see `row` as their next / previous active row
+                                if (i > row && (nb == 0 || i <= nb)) prv[k] = row;
                             }
                             ++qz;
                         } else {
                             if (lane == kr) { kact = sg > 0.0 ? 1 : -1; muK = mu_p; }
                             ++qk;
                         }
+                        PROF(7);
                         break;
                     }
                     // ============ partial step: working-set row lrow leaves ============
@@ -1056,7 +1078,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                             L.d1[lane] = vl_ - wa_; L.d2[lane] = (pb_ > 0 ? wb_ : 0.0) - vl_; L.d0[lane] = (pb_ > 0 ? wb_ : 0.0) - wa_;
                         }
                         WAVE_LDS_SYNC();
-                        const double g1 = idt2 / (double)(lrow - pa_), g2 = pb_ > 0 ? idt2 / (double)(pb_ - lrow) : 0.0, g0 = pb_ > 0 ? idt2 / (double)(pb_ - pa_) : 0.0;
+                        const double g1 = idt2 * frcp((double)(lrow - pa_)), g2 = pb_ > 0 ? idt2 * frcp((double)(pb_ - lrow)) : 0.0, g0 = pb_ > 0 ? idt2 * frcp((double)(pb_ - pa_)) : 0.0;
                         for (int e = lane; e < m * m; e += 64) {
                             const int i = e / m, jj = e - i * m;
                             L.G[e] -= g1 * L.d1[i] * L.d1[jj] + g2 * L.d2[i] * L.d2[jj] - g0 * L.d0[i] * L.d0[jj];
@@ -1065,9 +1087,9 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
 #pragma unroll
                         for (int k = 0; k < RL; ++k) {
                             const int i = lane * RL + k + 1;
-                            if (i == lrow) { sta[k] = 0; mu[k] = 0.0; prv[k] = 0; nxt[k] = 0; }
-                            if (i == pa_) nxt[k] = pb_;
-                            if (i == pb_) prv[k] = pa_;
+                            if (i == lrow) { sta[k] = 0; mu[k] = 0.0; }
+                            if (i >= pa_ && i < lrow) nxt[k] = pb_;
+                            if (i > lrow && (pb_ == 0 || i <= pb_)) prv[k] = pa_;
                         }
                         --qz;
                     } else {
@@ -1542,6 +1564,15 @@ int ismpc_a_rollout_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* sta
     }
     return 0;
 }
+
+#ifdef ISMPC_A_PROF
+int ismpc_a_debug_prof(unsigned long long* out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -2; }
+    return 0;
+}
+#endif
 
 int ismpc_a_feet_rows(const ismpc_a_handle* h) { return h ? h->feet.rows : -1; }
 

@@ -989,14 +989,17 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
 
 // 8 workgroups (one wavefront per SIMD each) must be co-resident per CU: <= 64 VGPRs and -- the binding one on
 // gfx950 -- <= 80 SGPRs (MI355X_MICROARCH.md "Residency": floor(800 / (ceil(sgpr/16)*16 + 16)) blocks per CU)
+#ifndef ISMPC_AFF_WAVES
+#define ISMPC_AFF_WAVES 4
+#endif
 template <int R>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
+__global__ __launch_bounds__(64 * ISMPC_AFF_WAVES) __attribute__((amdgpu_num_sgpr(80)))
 void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                        ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
                        unsigned char* zmark, int launch_id)
 {
     const int lane = threadIdx.x & 63;
-    const int gi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gi = blockIdx.x * ISMPC_AFF_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (gi >= batch) return;
     tick_affine_body<R, false>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
 }
@@ -1070,7 +1073,7 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
         const int lid = ++h->launch_id;
         const dim3 fgrid(std::min((batch + 3) / 4, 64));
 #define ISMPC_AFF(RR) do { \
-        hipLaunchKernelGGL(ismpc_tick_affine<RR>, grid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); \
+        hipLaunchKernelGGL(ismpc_tick_affine<RR>, dim3((batch + ISMPC_AFF_WAVES - 1) / ISMPC_AFF_WAVES), dim3(64 * ISMPC_AFF_WAVES), 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); \
         if (zm) hipLaunchKernelGGL(ismpc_tick_affine_fallback<RR>, fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); \
     } while (0)
         switch (R) {

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Per-phase shader-clock breakdown of the Formulation A wave kernel (library built with -DISMPC_A_PROF).
+usage: ISMPC_HIPCC_FLAGS=-DISMPC_A_PROF python -c 'from quadruped_gait_generation_ismpc_amd import build; build.build(force=True)'
+       python scripts/prof_a.py walk_C100 4096"""
+import ctypes as C, os, sys, subprocess
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from quadruped_gait_generation_ismpc_amd import _lib
+lib = _lib.load()
+prof = (C.c_ulonglong * 16)()
+lib.ismpc_a_debug_prof(prof, 1)
+sys.argv = [sys.argv[0]] + sys.argv[1:]
+exec(open(os.path.join(ROOT, "scripts", "bench_a.py")).read().replace("sys.exit(0)", "pass").split('z = np.load(os.path.join(ROOT, "tests", "golden", f"prerollA_{name}.npz"))')[0] if sys.argv[1] == "mc_C200" else open(os.path.join(ROOT, "scripts", "bench_a.py")).read())
+lib.ismpc_a_debug_prof(prof, 0)
+names = ["search", "new row+neighbours+h", "assemble K", "Gauss-Jordan", "comb/sv", "rho+ratio", "primal/dual step", "enter"]
+tot = sum(prof[k] for k in range(8))
+for k in range(8):
+    print(f"{names[k]:24s} {prof[k] / max(prof[8 + k], 1):9.0f} clk/visit  x{prof[8 + k]:9d}  {100.0 * prof[k] / tot:5.1f}%")
