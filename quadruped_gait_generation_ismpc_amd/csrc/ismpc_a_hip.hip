@@ -37,6 +37,7 @@ constexpr int QCAP = 264;              // capacity of the working set (>= C + F 
 
 struct DevA {
     int C, P, F, step, ds, n_gait, ncl, ldq, max_iter, sinv_in_lds;
+    int warm_add, warm_drop;           // block warm start of the wave kernel: passes that add + drop rows, passes that only drop
     double dt, eta, w, Qf, disp_forw, disp_forw_dummy, disp_L, aa, wP, sumw;
     double Au[9], Bu[3];
     const double *a, *PA, *wtail;      // stability row, its prefix sums PA[i] = sum_{k<i} a_k, tail weights (index i-(C+1))
@@ -551,8 +552,9 @@ template <int F> struct WaveLds {
     int    k1s[T];                     // first mapped footstep of every row
     double comb[F + 2];                // footstep-column coefficients seen by a row: comb[k1], comb[k1+1]
     double fl[F + 2];                  // f[0..F+1] with fl[0] = fl[F+1] = 0
+    double pf[F + 2];                  // the plan's footsteps (same layout): block warm start
+    double th[F * (F + 1) / 2 + 2 * F + 2];   // Gram sums of the block warm start: Theta (upper triangle), psi, gamma, sigma, gamma_E
     double G[m * m];                   // V' K^-1 V / dt^2 over the active ZMP rows
-    double K[2][m * (m + 1)];          // the small system, Gauss-Jordan ping-pong
     double vp[m], hx[m], d1[m], d2[m], d0[m], cc[m], mt[m];
 };
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -566,6 +568,13 @@ __device__ __forceinline__ int wave_max_i(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_min_i(int v) { return -wave_max_i(-v); }
+__device__ __forceinline__ int wave_scan_max_i(int v)      // inclusive prefix maximum over the 64 lanes
+{
+    const int lo = -2147483647 - 1;
+    v = max(v, dpp_i<0x111, 0xf>(lo, v)); v = max(v, dpp_i<0x112, 0xf>(lo, v)); v = max(v, dpp_i<0x114, 0xf>(lo, v));
+    v = max(v, dpp_i<0x118, 0xf>(lo, v)); v = max(v, dpp_i<0x142, 0xa>(lo, v)); v = max(v, dpp_i<0x143, 0xc>(lo, v));
+    return v;
+}
 __device__ __forceinline__ double wave_min_d(double v)
 {
     v = fmin(v, dpp64<0x111, 0xf, false>(INFINITY, v)); v = fmin(v, dpp64<0x112, 0xf, false>(INFINITY, v));
@@ -638,9 +647,9 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 
 // -DISMPC_A_PROF: per-phase shader-clock totals of the Goldfarb-Idnani loop (development aid, scripts/prof_a.py)
 #ifdef ISMPC_A_PROF
-__device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_prof[32];
 #define PROF_T0() unsigned long long pt_ = __builtin_readcyclecounter()
-#define PROF(k_) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (lane == 0 && (work & 127) == 0) { atomicAdd(&g_prof[k_], n_ - pt_); atomicAdd(&g_prof[8 + (k_)], 1ull); } pt_ = __builtin_readcyclecounter(); } while (0)
+#define PROF(k_) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (lane == 0 && (work & 127) == 0) { atomicAdd(&g_prof[k_], n_ - pt_); atomicAdd(&g_prof[16 + (k_)], 1ull); } pt_ = __builtin_readcyclecounter(); } while (0)
 #else
 #define PROF_T0() do {} while (0)
 #define PROF(k_) do {} while (0)
@@ -660,7 +669,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                        const ismpc_a_inst* __restrict__ ipar, const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch,
                        int* __restrict__ work_counter)
 {
-    constexpr int m = 2 * F + 1, NK = m * (m + 1), NE = (NK + 63) / 64;
+    constexpr int m = 2 * F + 1;
     __shared__ WaveLds<F> lds_all[T / 64];
     __shared__ double a_s[T], pa_s[T + 1];                  // stability row and its prefix sums: same for every QP of the handle
     __shared__ double a_pi[PI ? T / 64 : 1][PI ? T : 1], pa_pi[PI ? T / 64 : 1][PI ? T + 1 : 1];   // ... or one per wavefront
@@ -792,7 +801,251 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
             for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; u[k] = (i <= C) ? t0 * ap[i - 1] : 0.0; }
             muE = t0;
             for (int e = lane; e < m * m; e += 64) L.G[e] = 0.0;
+            if (lane <= F + 1) L.pf[lane] = fr;
             WAVE_LDS_SYNC();
+
+            // ---- small quasi-definite system  [[I+G11, G1x],[Gx1, Gxx - Sxx]] cc = rhs (L.hx), G in L.G; unknown order:
+            // 0..F-1 footstep columns, F = stability row, F+1..2F = Khat_1..F (rows outside kmask: pinned to 0).  Returns
+            // this lane's cc[lane] and leaves cc in L.cc.
+            auto solve_small = [&](const unsigned long long kmask) __attribute__((always_inline)) -> double {
+                // lane i < m owns row i of the augmented matrix in registers; the pivot row travels by readlane: no LDS
+                // traffic and no barriers inside the elimination
+                const int i = lane < m ? lane : m - 1;
+                const bool ipin = i > F && !((kmask >> (i - F)) & 1ull);
+                double Tr[m + 1];
+#pragma unroll
+                for (int jj = 0; jj < m; ++jj) {
+                    double val = L.G[i * m + jj];
+                    if (jj < F && i == jj) val += 1.0;
+                    if (jj == F && i == F) val -= aa;
+                    if (jj > F && i > F) {
+                        const int r1 = i - F, r2 = jj - F;
+                        val -= (r1 == r2) ? (r1 >= 2 ? 2.0 : 1.0) : ((r1 - r2 == 1 || r2 - r1 == 1) ? -1.0 : 0.0);
+                    }
+                    const bool jpin = jj > F && !((kmask >> (jj - F)) & 1ull);
+                    if (ipin || jpin) val = (i == jj) ? -1.0 : 0.0;
+                    Tr[jj] = val;
+                }
+                Tr[m] = ipin ? 0.0 : L.hx[i];
+#pragma unroll
+                for (int kk = 0; kk < m; ++kk) {                                 // Gauss-Jordan, no pivoting (quasi-definite)
+                    if (kk > F && !((kmask >> (kk - F)) & 1ull)) continue;       // pinned unknown: its column is already e_kk
+                    const double ipv = frcp(rl_d(Tr[kk], kk));
+                    const double fct = (lane == kk) ? 0.0 : Tr[kk] * ipv;
+#pragma unroll
+                    for (int jj = kk + 1; jj <= m; ++jj) Tr[jj] -= fct * rl_d(Tr[jj], kk);
+                }
+                double dg = Tr[0];
+#pragma unroll
+                for (int jj = 1; jj < m; ++jj) if (lane == jj) dg = Tr[jj];
+                const double cc_e = (lane < m) ? Tr[m] * frcp(dg) : 0.0;         // lane e: cc[e]
+                if (lane < m) L.cc[lane] = cc_e;
+                WAVE_LDS_SYNC();
+                return cc_e;
+            };
+
+            // ================= block warm start (primal-dual active-set passes) =================
+            // The loop below adds one row per iteration and a nominal tick ends with 40-70 active rows.  Before it, up to
+            // c.warm_add passes put every violated ZMP row into the working set at once (and take out rows whose multiplier
+            // is not positive), each followed by ONE structured solve for the whole set: G = V'K^-1 V and g = V'K^-1 c from
+            // one sweep over the active rows (K^-1 is tridiagonal: gaps only), the (F+1)-unknown system, a tridiagonal apply
+            // and a suffix sum.  Up to c.warm_drop more passes only remove rows with negative multipliers.  What is left is a
+            // valid starting pair for Goldfarb-Idnani (minimiser on its working set, multipliers >= 0), which finishes the
+            // job and owns the kinematic rows; if the passes do not get there the solve starts cold.  Same optimum either way.
+            if (c.warm_add > 0) {
+                constexpr int NG = (m * m + 63) / 64;
+                int gi_[NG], gj_[NG];
+#pragma unroll
+                for (int s_ = 0; s_ < NG; ++s_) { const int e = lane + 64 * s_; gi_[s_] = e / m; gj_[s_] = e - (e / m) * m; }
+                bool cold = false;
+                for (int pass = 0; ; ++pass) {
+                    const bool adding = pass < c.warm_add;
+                    PROF_T0();
+                    // ---- row values at the current point; the new working set
+                    if (lane <= F + 1) L.fl[lane] = fr;
+                    WAVE_LDS_SYNC();
+                    double lc = 0.0, cm[RL];
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) { lc += u[k]; cm[k] = lc; }
+                    const double bs = wave_scan_up(lc) - lc;
+                    bool changed = false;
+                    double cvr[RL];
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        cvr[k] = 0.0;
+                        if (i <= C) {
+                            int ns = sta[k];
+                            if (ns != 0) { if (adding ? !(mu[k] > 0.0) : (mu[k] < 0.0)) ns = 0; }
+                            else if (adding) {
+                                const double v = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + (1.0 - w1[k]) * L.fl[k1[k] + 1]);
+                                const double tol = 1e-11 * (fabs(v) + fmax(fabs(zlo[k]), fabs(zhi[k]))) + 1e-13;
+                                if (v - zlo[k] < -tol) ns = 1; else if (zhi[k] - v < -tol) ns = -1;
+                            }
+                            changed = changed || ns != sta[k];
+                            sta[k] = ns;
+                            // c_i = bound_i + M_i . plan footsteps
+                            if (ns != 0) cvr[k] = (ns > 0 ? zlo[k] : zhi[k]) + (w1[k] * L.pf[k1[k]] + (1.0 - w1[k]) * L.pf[k1[k] + 1]);
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(changed) == 0) break;          // a valid pair (and, while adding, nothing violated)
+                    if (pass >= c.warm_add + c.warm_drop) { cold = true; break; }  // no valid pair within the budget: start cold
+                    ++iters;
+                    // ---- previous / next active row of every row (active or not): exclusive max scan, exclusive suffix min scan
+                    int nact = 0;
+                    {
+                        int lmax = 0, lmin = 1 << 30;
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            const bool act = i <= C && sta[k] != 0;
+                            if (act) { lmax = max(lmax, i); lmin = min(lmin, i); }
+                            nact += __builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
+                            if (i <= C) L.sv[i - 1] = cvr[k];                    // c of every row, for its successor
+                        }
+                        int run = dpp_i<0x138, 0xf>(0, wave_scan_max_i(lmax));
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; prv[k] = run; if (i <= C && sta[k] != 0) run = i; }
+                        const int rev = __shfl(lmin, 63 - lane);
+                        const int ex = dpp_i<0x138, 0xf>(1 << 30, -wave_scan_max_i(-rev));
+                        const int nx = __shfl(ex, 63 - lane);
+                        run = (nx == (1 << 30)) ? 0 : nx;
+#pragma unroll
+                        for (int k = RL - 1; k >= 0; --k) { const int i = lane * RL + k + 1; nxt[k] = run; if (i <= C && sta[k] != 0) run = i; }
+                    }
+                    WAVE_LDS_SYNC();
+                    // ---- G = V'K^-1 V / dt^2 and g = V'K^-1 c / dt^2 as sums over consecutive active pairs (p, i) of
+                    // d d' / gap, d = V_i - V_p.  V_i = Phi(theta_i) + dt PA_i e_E with theta_i the row's mapping weights over the
+                    // F footstep columns and Phi a fixed sparse map, so everything follows from the Gram sums of
+                    // [dtheta (F) | dt dPA | dc] weighted by 1 / (dt^2 gap): each lane adds its own rows, one reduction per entry.
+                    {
+                        constexpr int NT = F * (F + 1) / 2, NS = NT + 2 * F + 2;
+                        double acc[NS];
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) acc[t] = 0.0;
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            if (i <= C && sta[k] != 0) {
+                                const int p_ = prv[k];
+                                int pk1 = -8; double pw1 = 0.0, ppa = 0.0, pc = 0.0;               // V_0 = 0, c_0 = 0
+                                if (p_ > 0) { pk1 = L.k1s[p_ - 1]; pw1 = L.w1s[p_ - 1]; ppa = pap[p_]; pc = L.sv[p_ - 1]; }
+                                const double pw2 = (p_ > 0) ? 1.0 - pw1 : 0.0, w2 = 1.0 - w1[k];
+                                const double om = idt2 * frcp((double)(i - p_));
+                                const double dE = dt * (pap[i] - ppa), dc = cvr[k] - pc;
+                                double dth[F];
+#pragma unroll
+                                for (int r = 1; r <= F; ++r) {
+                                    const double ti = (r == k1[k]) ? w1[k] : ((r == k1[k] + 1) ? w2 : 0.0);
+                                    const double tp = (r == pk1) ? pw1 : ((r == pk1 + 1) ? pw2 : 0.0);
+                                    dth[r - 1] = ti - tp;
+                                }
+                                int t = 0;
+#pragma unroll
+                                for (int r = 0; r < F; ++r) {
+                                    const double od = om * dth[r];
+#pragma unroll
+                                    for (int q = r; q < F; ++q) acc[t++] += od * dth[q];
+                                    acc[NT + r] += od * dE; acc[NT + F + r] += od * dc;
+                                }
+                                acc[NT + 2 * F] += om * dE * dE; acc[NT + 2 * F + 1] += om * dE * dc;
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) { const double v = wave_sum_d(acc[t]); if (lane == 0) L.th[t] = v; }
+                        WAVE_LDS_SYNC();
+                        // Phi(e): e < F -> +col e+1 ; e > F -> -col (e-F) + col (e-F-1) [if >= 1] ; all scaled by 1/sqrt(Qf)
+                        auto TH = [&](int r, int q) -> double {                       // Theta(r, q), 1-based, symmetric
+                            const int lo_ = min(r, q), hi_ = max(r, q);
+                            return L.th[(lo_ - 1) * F - ((lo_ - 1) * (lo_ - 2)) / 2 + (hi_ - lo_)];
+                        };
+#pragma unroll
+                        for (int s_ = 0; s_ < NG; ++s_) {
+                            const int e = lane + 64 * s_;
+                            if (e < m * m) {
+                                const int i_ = gi_[s_], j_ = gj_[s_];
+                                const int ra = i_ < F ? i_ + 1 : i_ - F, rb = j_ < F ? j_ + 1 : j_ - F;     // leading column of Phi(e)
+                                const double sa = i_ < F ? 1.0 : -1.0, sb = j_ < F ? 1.0 : -1.0;
+                                const bool a2 = i_ > F && ra >= 2, b2 = j_ > F && rb >= 2;                   // second term: +col (r-1)
+                                double val;
+                                if (i_ == F && j_ == F) val = L.th[NT + 2 * F];
+                                else if (i_ == F || j_ == F) {
+                                    const int r_ = (i_ == F) ? rb : ra; const double s1 = (i_ == F) ? sb : sa; const bool t2 = (i_ == F) ? b2 : a2;
+                                    val = s1 * L.th[NT + r_ - 1];
+                                    if (t2) val += L.th[NT + r_ - 2];
+                                    val *= isq;
+                                } else {
+                                    val = sa * sb * TH(ra, rb);
+                                    if (a2) val += sb * TH(ra - 1, rb);
+                                    if (b2) val += sa * TH(ra, rb - 1);
+                                    if (a2 && b2) val += TH(ra - 1, rb - 1);
+                                    val *= isq * isq;
+                                }
+                                L.G[e] = val;
+                            }
+                        }
+                        if (lane < m) {
+                            double gv;
+                            if (lane == F) gv = L.th[NT + 2 * F + 1] - beq;
+                            else {
+                                const int ra = lane < F ? lane + 1 : lane - F;
+                                gv = (lane < F ? 1.0 : -1.0) * L.th[NT + F + ra - 1];
+                                if (lane > F && ra >= 2) gv += L.th[NT + F + ra - 2];
+                                gv *= isq;
+                            }
+                            L.hx[lane] = gv;
+                        }
+                    }
+                    WAVE_LDS_SYNC();
+                    (void)solve_small(0ull);                                     // kinematic rows stay out of the block phase
+                    const double cEw = L.cc[F];
+                    // comb[r] = cc[r-1] / sqrt(Qf), r = 1..F: what a row sees through its two footstep columns
+                    if (lane <= F + 1) L.comb[lane] = klane ? L.cc[lane - 1] * isq : 0.0;
+                    WAVE_LDS_SYNC();
+                    double sl[RL];                                               // s_i = c_i - V_i . cc on the active rows
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        sl[k] = 0.0;
+                        if (i <= C && sta[k] != 0)
+                            sl[k] = cvr[k] - (w1[k] * L.comb[k1[k]] + (1.0 - w1[k]) * L.comb[k1[k] + 1]) - dt * pap[i] * cEw;
+                        if (i <= C) L.sv[i - 1] = sl[k];
+                    }
+                    WAVE_LDS_SYNC();
+                    // multipliers (tridiagonal K^-1), u = dt suffix(lambda) + lambda_E a, f = plan - comb
+                    double ls = 0.0, suf[RL];
+#pragma unroll
+                    for (int k = RL - 1; k >= 0; --k) {
+                        const int i = lane * RL + k + 1;
+                        double r_ = 0.0;
+                        if (i <= C && sta[k] != 0) {
+                            const double sp = prv[k] > 0 ? L.sv[prv[k] - 1] : 0.0;
+                            r_ = (sl[k] - sp) * frcp((double)(i - prv[k]));
+                            if (nxt[k] > 0) r_ -= (L.sv[nxt[k] - 1] - sl[k]) * frcp((double)(nxt[k] - i));
+                            r_ *= idt2;
+                        }
+                        mu[k] = sta[k] > 0 ? r_ : -r_;
+                        ls += dt * r_; suf[k] = ls;
+                    }
+                    const double incl = wave_scan_up(ls);
+                    const double above = rl_d(incl, 63) - incl;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; u[k] = (i <= C) ? (suf[k] + above) + cEw * ap[i - 1] : 0.0; }
+                    if (klane) fr = L.pf[lane] - L.comb[lane];
+                    muE = cEw;
+                    qz = nact;
+                    WAVE_LDS_SYNC();
+                    PROF(8);
+                }
+                if (cold) {
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; sta[k] = 0; mu[k] = 0.0; prv[k] = 0; nxt[k] = 0; u[k] = (i <= C) ? t0 * ap[i - 1] : 0.0; }
+                    if (klane) fr = L.pf[lane];
+                    muE = t0; qz = 0;
+                    for (int e = lane; e < m * m; e += 64) L.G[e] = 0.0;
+                    WAVE_LDS_SYNC();
+                }
+            }
 
             for (;;) {
                 PROF_T0();
@@ -895,52 +1148,9 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                     WAVE_LDS_SYNC();
                     PROF(1);
                     const unsigned long long kmask = __builtin_amdgcn_ballot_w64(klane && kact != 0);   // bit r: Khat_r active
-#pragma unroll
-                    for (int s_ = 0; s_ < NE; ++s_) {
-                        const int e = lane + 64 * s_;
-                        if (e < NK) {
-                            const int i = e / (m + 1), jj = e - i * (m + 1);
-                            const bool ipin = i > F && !((kmask >> (i - F)) & 1ull);
-                            const bool jpin = jj > F && jj < m && !((kmask >> (jj - F)) & 1ull);
-                            double val;
-                            if (jj < m) {
-                                val = L.G[i * m + jj];
-                                if (i < F && jj == i) val += 1.0;
-                                if (i == F && jj == F) val -= aa;
-                                if (i > F && jj > F) {
-                                    const int r1 = i - F, r2 = jj - F;
-                                    val -= (r1 == r2) ? (r1 >= 2 ? 2.0 : 1.0) : ((r1 - r2 == 1 || r2 - r1 == 1) ? -1.0 : 0.0);
-                                }
-                                if (ipin || jpin) val = (i == jj) ? -1.0 : 0.0;
-                            } else val = ipin ? 0.0 : L.hx[i];
-                            L.K[0][e] = val;
-                        }
-                    }
-                    WAVE_LDS_SYNC();
-                    PROF(2);
-                    int cur_buf = 0;
-#pragma nounroll
-                    for (int kk = 0; kk < m; ++kk) {                              // Gauss-Jordan, no pivoting (quasi-definite)
-                        if (kk > F && !((kmask >> (kk - F)) & 1ull)) continue;    // pinned unknown: its column is already e_kk
-                        const double* Ks = L.K[cur_buf]; double* Kd = L.K[cur_buf ^ 1];
-                        const double ipv = frcp(Ks[kk * (m + 1) + kk]);
-#pragma unroll
-                        for (int s_ = 0; s_ < NE; ++s_) {
-                            const int e = lane + 64 * s_;
-                            if (e < NK) {
-                                const int i = e / (m + 1), jj = e - i * (m + 1);
-                                Kd[e] = (i != kk && jj > kk) ? Ks[e] - Ks[i * (m + 1) + kk] * Ks[kk * (m + 1) + jj] * ipv : Ks[e];
-                            }
-                        }
-                        cur_buf ^= 1;
-                        WAVE_LDS_SYNC();
-                    }
-                    const double* Kf = L.K[cur_buf];
-                    const double cc_e = (lane < m) ? Kf[lane * (m + 1) + m] * frcp(Kf[lane * (m + 1) + lane]) : 0.0;   // lane e: cc[e]
-                    if (lane < m) L.cc[lane] = cc_e;
-                    WAVE_LDS_SYNC();
+                    const double cc_e = solve_small(kmask);
                     const double cE = L.cc[F];
-                    PROF(3);
+                    PROF(2);
                     // ---- y = coefficients on the V columns (delta_Z - V cc = sg dt^2 k_i + V y); rows see the footstep
                     // columns through comb[k1], comb[k1+1]:  comb[r] = (yM_r - yK_r + yK_{r+1}) / sqrt(Qf)
                     if (lane <= F + 1) {
@@ -1400,6 +1610,12 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     c.disp_forw = p->disp_forw; c.disp_forw_dummy = p->disp_forw_dummy; c.disp_L = p->disp_L;
     c.ldq = (p->C + p->F + 2) | 1;                        // odd leading dimension: conflict-free LDS columns
     c.max_iter = 20 * (p->C + p->F) + 200;
+    c.warm_add = 3; c.warm_drop = 6;                      // ISMPC_A_WARM=add,drop overrides; ISMPC_A_WARM=0 starts every QP cold
+    if (const char* e = std::getenv("ISMPC_A_WARM")) {
+        int a_ = 0, d_ = 0;
+        const int got = std::sscanf(e, "%d,%d", &a_, &d_);
+        if (got >= 1) { c.warm_add = std::max(0, std::min(a_, 32)); c.warm_drop = got >= 2 ? std::max(0, std::min(d_, 32)) : 6; }
+    }
     // S^-1 lives in an L2-resident scratch slab (4 workgroups per CU); ISMPC_A_SINV=lds keeps it in LDS instead when it
     // fits next to the static block (then 1 workgroup per CU).  Measured on MI355X (walk, C=100, batch 16 384):
     // scratch 2.8e5 ticks/s, LDS 2.0e5 ticks/s -- the kernel is barrier-latency bound, concurrency wins.
@@ -1566,10 +1782,10 @@ int ismpc_a_rollout_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* sta
 }
 
 #ifdef ISMPC_A_PROF
-int ismpc_a_debug_prof(unsigned long long* out16, int reset)
+int ismpc_a_debug_prof(unsigned long long* out32, int reset)
 {
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -2; }
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -2;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -2; }
     return 0;
 }
 #endif

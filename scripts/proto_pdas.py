@@ -74,3 +74,103 @@ if __name__ == "__main__":
         sim.state = st
     tot = np.array(tot)
     print("mean passes", tot[:, 0].mean(), "max", tot[:, 0].max(), "unconverged", int(((tot[:, 2] > 0) | (tot[:, 3] > 0)).sum()), "of", len(tot))
+
+
+def gi_from(H, g, E, b, N, lo, hi, W, x, mu, max_steps=1000):
+    """Dense Goldfarb-Idnani continuation from the S-pair (x, W, mu >= 0).  Returns (x, W, steps)."""
+    Hi = 1.0 / H
+    W = dict(W); mu = dict(mu); steps = 0
+    nrm = np.sqrt(((N * N) * Hi).sum(1))
+    while True:
+        cv = N @ x
+        tol = 1e-11 * (np.abs(cv) + np.maximum(np.abs(lo), np.abs(hi))) + 1e-13
+        vl = cv - lo; vh = hi - cv
+        cand = np.zeros(len(cv)); sgn = np.zeros(len(cv))
+        for r in range(len(cv)):
+            if r in W: continue
+            if vl[r] < -tol[r] and vl[r] / nrm[r] < cand[r]: cand[r] = vl[r] / nrm[r]; sgn[r] = +1
+            if vh[r] < -tol[r] and vh[r] / nrm[r] < cand[r]: cand[r] = vh[r] / nrm[r]; sgn[r] = -1
+        p = int(np.argmin(cand))
+        if cand[p] >= 0: return x, W, steps
+        sg = sgn[p]; n = sg * N[p]                      # constraint n.x >= sg*bound
+        viol = (vl[p] if sg > 0 else vh[p])
+        mu_p = 0.0
+        while True:
+            steps += 1
+            if steps > max_steps: raise RuntimeError("GI stuck")
+            rows = sorted(W)
+            A_ = np.vstack([E] + [W[r] * N[r] for r in rows])
+            S = (A_ * Hi) @ A_.T
+            d = A_ @ (Hi * n)
+            r_ = np.linalg.solve(S, d)
+            z = Hi * n - Hi * (A_.T @ r_)
+            zn = z @ n
+            t1 = np.inf; lrow = None
+            for k, r in enumerate(rows):
+                if r_[k + 1] > 0:
+                    tt = mu[r] / r_[k + 1]
+                    if tt < t1: t1 = tt; lrow = r
+            t2 = -viol / zn if zn > 1e-12 * (n @ (Hi * n)) else np.inf
+            t = min(t1, t2)
+            if not np.isfinite(t): raise RuntimeError("infeasible")
+            if np.isfinite(t2): x = x + t * z
+            for k, r in enumerate(rows): mu[r] -= t * r_[k + 1]
+            mu_p += t
+            if np.isfinite(t2) and t == t2:
+                W[p] = int(sg); mu[p] = mu_p; break
+            del W[lrow]; del mu[lrow]
+            cvp = N[p] @ x
+            viol = (cvp - lo[p]) if sg > 0 else (hi[p] - cvp)
+
+
+def hybrid(H, g, E, b, N, lo, hi, passes, cleanup=6):
+    """PDAS passes, then drop-negative clean-up, then GI.  Returns (work in GI-step equivalents, detail)."""
+    W = {}; x, mu = solve_on(H, g, E, b, N, lo, hi, W)
+    npass = 0
+    for p in range(passes):
+        cv = N @ x
+        tol = 1e-11 * (np.abs(cv) + np.maximum(np.abs(lo), np.abs(hi))) + 1e-13
+        new = {r: s for r, s in W.items() if mu[r] > 0}
+        for r in np.nonzero(cv < lo - tol)[0]: new.setdefault(int(r), +1)
+        for r in np.nonzero(cv > hi + tol)[0]: new.setdefault(int(r), -1)
+        if new == W: break
+        W = new; x, mu = solve_on(H, g, E, b, N, lo, hi, W); npass += 1
+    ncl = 0
+    while any(v < 0 for v in mu.values()):
+        if ncl >= cleanup:                                   # give up: cold start
+            W = {}; x, mu = solve_on(H, g, E, b, N, lo, hi, W); ncl += 1; break
+        W = {r: s for r, s in W.items() if mu[r] >= 0}
+        x, mu = solve_on(H, g, E, b, N, lo, hi, W); ncl += 1
+    x, W2, steps = gi_from(H, g, E, b, N, lo, hi, W, x, mu)
+    return npass, ncl, steps, x, W2
+
+
+def study(name, ntest, passes_list=(0, 1, 2, 3, 4, 6)):
+    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"prerollA_{name}.npz"))
+    kind = int(z["gait"]); p = A.params(kind, C_=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
+    sim = A.SimA(A.gait(kind, float(z["phi"]), float(z["disp_A"])), p, backend="gi")
+    rng = np.random.default_rng(0)
+    sim.run(int(rng.integers(5, 150)))
+    res = {P: [] for P in passes_list}
+    for t in range(ntest):
+        sim.run(int(rng.integers(1, 12)))
+        st = sim.state.copy()
+        st2 = st.copy(); st2["xd"] += rng.uniform(-0.03, 0.03); st2["yd"] += rng.uniform(-0.05, 0.05)
+        sim.state = st2
+        for axis in (0, 1):
+            D = sim.axis_data(axis)
+            Q = build(D, p.dt, p.Qf)
+            xs = None
+            for P in passes_list:
+                npass, ncl, steps, x, W = hybrid(*Q, P)
+                if xs is None: xs = x
+                assert np.abs(x - xs).max() < 1e-7 * max(1, np.abs(xs).max()), (P, np.abs(x - xs).max())
+                res[P].append((npass, ncl, steps))
+        sim.state = st
+    for P in passes_list:
+        r = np.array(res[P])
+        print(f"{name} passes<={P}: pdas {r[:,0].mean():.2f} cleanup {r[:,1].mean():.2f} GI steps {r[:,2].mean():.1f}  "
+              f"work(2/pass) {(2 * (r[:,0] + r[:,1]) + r[:,2]).mean():.1f}   max GI {r[:,2].max()}")
+
+if __name__ == "__main__" and os.environ.get("STUDY"):
+    study(sys.argv[1] if len(sys.argv) > 1 else "walk_C100", int(sys.argv[2]) if len(sys.argv) > 2 else 20)
