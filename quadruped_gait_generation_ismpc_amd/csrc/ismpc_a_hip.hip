@@ -37,7 +37,7 @@ constexpr int QCAP = 264;              // capacity of the working set (>= C + F 
 
 struct DevA {
     int C, P, F, step, ds, n_gait, ncl, ldq, max_iter, sinv_in_lds;
-    int warm_add, warm_drop;           // block warm start of the wave kernel: passes that add + drop rows, passes that only drop
+    int warm_add, warm_drop, warm_extra; // block warm start of the wave kernel: passes that add + drop rows, passes that only drop, re-entries
     double dt, eta, w, Qf, disp_forw, disp_forw_dummy, disp_L, aa, wP, sumw;
     double Au[9], Bu[3];
     const double *a, *PA, *wtail;      // stability row, its prefix sums PA[i] = sum_{k<i} a_k, tail weights (index i-(C+1))
@@ -857,9 +857,11 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 int gi_[NG], gj_[NG];
 #pragma unroll
                 for (int s_ = 0; s_ < NG; ++s_) { const int e = lane + 64 * s_; gi_[s_] = e / m; gj_[s_] = e - (e / m) * m; }
-                bool cold = false;
+                bool cold = false, force_add = false;
+                int peel = 1, extra = c.warm_extra, nsolve = 0;
                 for (int pass = 0; ; ++pass) {
-                    const bool adding = pass < c.warm_add;
+                    const bool adding = pass < c.warm_add || force_add;
+                    force_add = false;
                     PROF_T0();
                     // ---- row values at the current point; the new working set
                     if (lane <= F + 1) L.fl[lane] = fr;
@@ -868,6 +870,51 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
 #pragma unroll
                     for (int k = 0; k < RL; ++k) { lc += u[k]; cm[k] = lc; }
                     const double bs = wave_scan_up(lc) - lc;
+                    // ---- rows that leave: multiplier not positive (while adding) / negative (drop-only passes).  Such a row
+                    // usually sits at the end of a run of consecutive rows on the same bound, and the run has to shrink by
+                    // more than one row ("peeling"): every pass in a row that still finds one doubles the number of rows
+                    // taken off that end (peel).  Taking off too many is harmless, they come back as violated rows.
+                    bool xdrop[RL], negr[RL], anyneg = false;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        negr[k] = sta[k] != 0 && (adding ? !(mu[k] > 0.0) : (mu[k] < 0.0));
+                        xdrop[k] = false; anyneg = anyneg || negr[k];
+                    }
+                    const bool wave_neg = __builtin_amdgcn_ballot_w64(anyneg) != 0;
+                    if (peel > 1 && wave_neg) {
+                        const int sprev = dpp_i<0x138, 0xf>(0, sta[RL - 1]), snext = dpp_i<0x130, 0xf>(0, sta[0]);
+                        int lst = 0, len_ = 1 << 30;                            // this lane's last run start / first run end
+                        bool isst[RL], isen[RL];
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            const int sb = k > 0 ? sta[k - 1] : sprev, sa = k < RL - 1 ? sta[k + 1] : snext;
+                            isst[k] = sta[k] != 0 && sb != sta[k]; isen[k] = sta[k] != 0 && sa != sta[k];
+                            if (isst[k]) lst = i;
+                            if (isen[k]) len_ = min(len_, i);
+                            if (i <= C) L.sv[i - 1] = negr[k] ? 1.0 : 0.0;
+                        }
+                        int runlo[RL], runhi[RL];
+                        int run = dpp_i<0x138, 0xf>(0, wave_scan_max_i(lst));
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; if (isst[k]) run = i; runlo[k] = run; }
+                        const int rev = __shfl(len_, 63 - lane);
+                        const int ex = dpp_i<0x138, 0xf>(1 << 30, -wave_scan_max_i(-rev));
+                        run = __shfl(ex, 63 - lane);
+#pragma unroll
+                        for (int k = RL - 1; k >= 0; --k) { const int i = lane * RL + k + 1; if (isen[k]) run = i; runhi[k] = run; }
+                        WAVE_LDS_SYNC();
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            if (sta[k] != 0 && runlo[k] >= 1 && runhi[k] <= C && runlo[k] != runhi[k]) {
+                                if (i - runlo[k] < peel && L.sv[runlo[k] - 1] != 0.0) xdrop[k] = true;
+                                if (runhi[k] - i < peel && L.sv[runhi[k] - 1] != 0.0) xdrop[k] = true;
+                            }
+                        }
+                        WAVE_LDS_SYNC();
+                    }
+                    peel = wave_neg ? min(2 * peel, 64) : 1;
                     bool changed = false;
                     double cvr[RL];
 #pragma unroll
@@ -876,7 +923,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         cvr[k] = 0.0;
                         if (i <= C) {
                             int ns = sta[k];
-                            if (ns != 0) { if (adding ? !(mu[k] > 0.0) : (mu[k] < 0.0)) ns = 0; }
+                            if (ns != 0) { if (negr[k] || xdrop[k]) ns = 0; }
                             else if (adding) {
                                 const double v = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + (1.0 - w1[k]) * L.fl[k1[k] + 1]);
                                 const double tol = 1e-11 * (fabs(v) + fmax(fabs(zlo[k]), fabs(zhi[k]))) + 1e-13;
@@ -888,9 +935,12 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                             if (ns != 0) cvr[k] = (ns > 0 ? zlo[k] : zhi[k]) + (w1[k] * L.pf[k1[k]] + (1.0 - w1[k]) * L.pf[k1[k] + 1]);
                         }
                     }
-                    if (__builtin_amdgcn_ballot_w64(changed) == 0) break;          // a valid pair (and, while adding, nothing violated)
-                    if (pass >= c.warm_add + c.warm_drop) { cold = true; break; }  // no valid pair within the budget: start cold
-                    ++iters;
+                    if (__builtin_amdgcn_ballot_w64(changed) == 0) {               // a valid pair (and, while adding, nothing violated)
+                        if (!adding && extra > 0) { --extra; force_add = true; continue; }   // valid after drop-only passes: one more adding pass
+                        break;
+                    }
+                    if (nsolve >= c.warm_add + c.warm_drop + c.warm_extra * (1 + c.warm_drop)) { cold = true; break; }   // budget spent: start cold
+                    ++nsolve; ++iters;
                     // ---- previous / next active row of every row (active or not): exclusive max scan, exclusive suffix min scan
                     int nact = 0;
                     {
@@ -1038,6 +1088,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                     PROF(8);
                 }
                 if (cold) {
+                    { PROF_T0(); PROF(9); }
 #pragma unroll
                     for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; sta[k] = 0; mu[k] = 0.0; prv[k] = 0; nxt[k] = 0; u[k] = (i <= C) ? t0 * ap[i - 1] : 0.0; }
                     if (klane) fr = L.pf[lane];
@@ -1610,11 +1661,13 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     c.disp_forw = p->disp_forw; c.disp_forw_dummy = p->disp_forw_dummy; c.disp_L = p->disp_L;
     c.ldq = (p->C + p->F + 2) | 1;                        // odd leading dimension: conflict-free LDS columns
     c.max_iter = 20 * (p->C + p->F) + 200;
-    c.warm_add = 3; c.warm_drop = 6;                      // ISMPC_A_WARM=add,drop overrides; ISMPC_A_WARM=0 starts every QP cold
+    c.warm_add = 4; c.warm_drop = 6; c.warm_extra = 0;    // ISMPC_A_WARM=add,drop,extra overrides; ISMPC_A_WARM=0 starts every QP cold
     if (const char* e = std::getenv("ISMPC_A_WARM")) {
-        int a_ = 0, d_ = 0;
-        const int got = std::sscanf(e, "%d,%d", &a_, &d_);
-        if (got >= 1) { c.warm_add = std::max(0, std::min(a_, 32)); c.warm_drop = got >= 2 ? std::max(0, std::min(d_, 32)) : 6; }
+        int a_ = 0, d_ = 0, x_ = 0;
+        const int got = std::sscanf(e, "%d,%d,%d", &a_, &d_, &x_);
+        if (got >= 1) c.warm_add = std::max(0, std::min(a_, 32));
+        if (got >= 2) c.warm_drop = std::max(0, std::min(d_, 32));
+        if (got >= 3) c.warm_extra = std::max(0, std::min(x_, 8));
     }
     // S^-1 lives in an L2-resident scratch slab (4 workgroups per CU); ISMPC_A_SINV=lds keeps it in LDS instead when it
     // fits next to the static block (then 1 workgroup per CU).  Measured on MI355X (walk, C=100, batch 16 384):

@@ -174,3 +174,81 @@ def study(name, ntest, passes_list=(0, 1, 2, 3, 4, 6)):
 
 if __name__ == "__main__" and os.environ.get("STUDY"):
     study(sys.argv[1] if len(sys.argv) > 1 else "walk_C100", int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+
+
+def runs_of(W, C):
+    """contiguous same-sign runs of active ZMP rows (0-based dense rows < C): dict row -> (lo, hi)."""
+    out = {}
+    rows = sorted(r for r in W if r < C)
+    k = 0
+    while k < len(rows):
+        j = k
+        while j + 1 < len(rows) and rows[j + 1] == rows[j] + 1 and W[rows[j + 1]] == W[rows[k]]: j += 1
+        for t in range(k, j + 1): out[rows[t]] = (rows[k], rows[j])
+        k = j + 1
+    return out
+
+
+def hybrid2(H, g, E, b, N, lo, hi, C, max_add, max_drop, grow=2, cap=64, strict_ends=False):
+    """PDAS passes with geometric peeling at run ends; drop-only passes at the end; then GI.  (passes, cold, GI steps, x)"""
+    W = {}; x, mu = solve_on(H, g, E, b, N, lo, hi, W)
+    D = 1; npass = 0; cold = 0
+    for p in range(max_add + max_drop + 1):
+        adding = p < max_add
+        neg = {r for r in W if (mu[r] <= 0 if adding else mu[r] < 0)}
+        drop = set(neg)
+        rn = runs_of(W, C)
+        ends = True
+        for r in neg:
+            if r not in rn:
+                if strict_ends: ends = False
+                continue
+            l, h = rn[r]
+            if r == l and r != h: drop |= set(range(l, min(h, l + D - 1) + 1))
+            elif r == h and r != l: drop |= set(range(max(l, h - D + 1), h + 1))
+            elif l == h: pass
+            elif strict_ends: ends = False
+        new = {r: s for r, s in W.items() if r not in drop}
+        if adding:
+            cv = N @ x
+            tol = 1e-11 * (np.abs(cv) + np.maximum(np.abs(lo), np.abs(hi))) + 1e-13
+            for r in np.nonzero(cv[:C] < (lo - tol)[:C])[0]: new.setdefault(int(r), +1)
+            for r in np.nonzero(cv[:C] > (hi + tol)[:C])[0]: new.setdefault(int(r), -1)
+        if new == W: break
+        if p >= max_add + max_drop:
+            W = {}; x, mu = solve_on(H, g, E, b, N, lo, hi, W); cold = 1; break
+        D = min(D * grow, cap) if (neg and ends) else 1
+        W = new; x, mu = solve_on(H, g, E, b, N, lo, hi, W); npass += 1
+    x, W2, steps = gi_from(H, g, E, b, N, lo, hi, W, x, mu)
+    return npass, cold, steps, x
+
+
+def study2(name, ntest, cfgs=((12, 8, 1), (12, 8, 2), (6, 6, 2), (4, 6, 2), (8, 8, 2))):
+    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"prerollA_{name}.npz"))
+    kind = int(z["gait"]); p = A.params(kind, C_=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
+    sim = A.SimA(A.gait(kind, float(z["phi"]), float(z["disp_A"])), p, backend="gi")
+    rng = np.random.default_rng(0)
+    sim.run(int(rng.integers(5, 150)))
+    res = {c: [] for c in cfgs}
+    for t in range(ntest):
+        sim.run(int(rng.integers(1, 12)))
+        st = sim.state.copy()
+        st2 = st.copy(); st2["xd"] += rng.uniform(-0.03, 0.03); st2["yd"] += rng.uniform(-0.05, 0.05)
+        sim.state = st2
+        for axis in (0, 1):
+            D = sim.axis_data(axis)
+            Q = build(D, p.dt, p.Qf)
+            xs = None
+            for c in cfgs:
+                npass, cold, steps, x = hybrid2(*Q, p.C, c[0], c[1], grow=c[2])
+                if xs is None: xs = x
+                assert np.abs(x - xs).max() < 1e-7 * max(1, np.abs(xs).max()), (c, np.abs(x - xs).max())
+                res[c].append((npass, cold, steps))
+        sim.state = st
+    for c in cfgs:
+        r = np.array(res[c])
+        print(f"{name} add<={c[0]} drop<={c[1]} grow={c[2]}: passes {r[:,0].mean():.2f} cold {r[:,1].mean():.2f} GI steps {r[:,2].mean():.1f}  "
+              f"work(1.2/pass) {(1.2 * r[:,0] + r[:,2]).mean():.1f}   max GI {r[:,2].max()}")
+
+if __name__ == "__main__" and os.environ.get("STUDY2"):
+    study2(sys.argv[1] if len(sys.argv) > 1 else "walk_C100", int(sys.argv[2]) if len(sys.argv) > 2 else 20)
