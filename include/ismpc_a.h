@@ -37,6 +37,9 @@ extern "C" {
 #define ISMPC_A_ST_BAD_INDEX     8    /* j + P beyond the centreline, fc + F beyond the plan, or j outside
                                          the current step [step (fc-1), step fc - 1]               */
 #define ISMPC_A_ST_ITER_LIMIT    16   /* active-set iteration limit hit (result is the last iterate)  */
+#define ISMPC_A_ST_UNVERIFIED    32   /* set together with X/Y_INFEASIBLE when the flag comes from the final check of
+                                         the returned point (a row, a kinematic limit or the stability row is off by
+                                         more than 1e-7 relative) and not from the active-set logic itself */
 
 typedef struct ismpc_a_gait {           /* init_quadruped*.m:5-37 */
     int32_t gait;                       /* 0 = trot (init_quadruped.m), 1 = walk (init_quadruped2.m) */

@@ -915,17 +915,22 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                         WAVE_LDS_SYNC();
                     }
                     peel = wave_neg ? min(2 * peel, 64) : 1;
-                    bool changed = false;
-                    double cvr[RL];
+                    bool changed = false, off_bound = false;
+                    double cvr[RL], aul = 0.0;
 #pragma unroll
                     for (int k = 0; k < RL; ++k) {
                         const int i = lane * RL + k + 1;
                         cvr[k] = 0.0;
                         if (i <= C) {
                             int ns = sta[k];
-                            if (ns != 0) { if (negr[k] || xdrop[k]) ns = 0; }
-                            else if (adding) {
-                                const double v = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + (1.0 - w1[k]) * L.fl[k1[k] + 1]);
+                            const double v = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + (1.0 - w1[k]) * L.fl[k1[k] + 1]);
+                            aul += ap[i - 1] * u[k];
+                            if (ns != 0) {
+                                // an active row must sit on its bound after the block solve; if it does not, the solve broke down
+                                const double bd = ns > 0 ? zlo[k] : zhi[k];
+                                off_bound = off_bound || !(fabs(v - bd) <= 1e-8 * (fabs(v) + fabs(bd)) + 1e-10);
+                                if (negr[k] || xdrop[k]) ns = 0;
+                            } else if (adding) {
                                 const double tol = 1e-11 * (fabs(v) + fmax(fabs(zlo[k]), fabs(zhi[k]))) + 1e-13;
                                 if (v - zlo[k] < -tol) ns = 1; else if (zhi[k] - v < -tol) ns = -1;
                             }
@@ -934,6 +939,10 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                             // c_i = bound_i + M_i . plan footsteps
                             if (ns != 0) cvr[k] = (ns > 0 ? zlo[k] : zhi[k]) + (w1[k] * L.pf[k1[k]] + (1.0 - w1[k]) * L.pf[k1[k] + 1]);
                         }
+                    }
+                    if (nsolve > 0) {
+                        const double eqr = wave_sum_d(aul) - beq;                  // ... and the stability row must hold
+                        if (__builtin_amdgcn_ballot_w64(off_bound) != 0 || !(fabs(eqr) <= 1e-8 * (1.0 + fabs(beq)))) { cold = true; break; }
                     }
                     if (__builtin_amdgcn_ballot_w64(changed) == 0) {               // a valid pair (and, while adding, nothing violated)
                         if (!adding && extra > 0) { --extra; force_add = true; continue; }   // valid after drop-only passes: one more adding pass
@@ -1360,6 +1369,38 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 }
                 if (failed) break;
             }
+        }
+
+        // ---- every row, active or not, the kinematic rows and the stability row are checked once more at the point that
+        // is about to be returned: a working set that pins (nearly) every variable of an infeasible QP can break the small
+        // solves down without any inactive row showing it.  Such a QP is reported infeasible (the reference's quadprog
+        // returns no solution there).
+        if (status == 0) {
+            if (lane <= F + 1) L.fl[lane] = fr;
+            WAVE_LDS_SYNC();
+            double lc = 0.0, cm[RL], aul = 0.0;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) { lc += u[k]; cm[k] = lc; }
+            const double bs = wave_scan_up(lc) - lc;
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) {
+                const int i = lane * RL + k + 1;
+                if (i <= C) {
+                    const double v = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + (1.0 - w1[k]) * L.fl[k1[k] + 1]);
+                    const double tol = 1e-7 * (fabs(v) + fmax(fabs(zlo[k]), fabs(zhi[k]))) + 1e-9;
+                    bad = bad || !(v - zlo[k] >= -tol && zhi[k] - v >= -tol);
+                    aul += ap[i - 1] * u[k];
+                }
+            }
+            const double fprev = dpp64<0x111, 0xf, true>(0.0, fr);
+            if (klane && khi < INFINITY) {
+                const double v = fr - fprev, tol = 1e-7 * (fabs(v) + fmax(fabs(klo), fabs(khi))) + 1e-9;
+                bad = bad || !(v - klo >= -tol && khi - v >= -tol);
+            }
+            const double eqr = wave_sum_d(aul) - beq;
+            if (__builtin_amdgcn_ballot_w64(bad) != 0 || !(fabs(eqr) <= 1e-7 * (1.0 + fabs(beq))))
+                status |= (axis == 0 ? ISMPC_A_ST_X_INFEASIBLE : ISMPC_A_ST_Y_INFEASIBLE) | ISMPC_A_ST_UNVERIFIED;
         }
 
         // ---- LIP update (:297-322), footstep bookkeeping (:522-556), outputs

@@ -9,7 +9,7 @@ import numpy as np
 from . import _lib
 
 TROT, WALK = 0, 1
-ST_X_INFEASIBLE, ST_Y_INFEASIBLE, ST_OVERFLOW, ST_BAD_INDEX, ST_ITER_LIMIT = 1, 2, 4, 8, 16
+ST_X_INFEASIBLE, ST_Y_INFEASIBLE, ST_OVERFLOW, ST_BAD_INDEX, ST_ITER_LIMIT, ST_UNVERIFIED = 1, 2, 4, 8, 16, 32
 
 
 class GaitA(C.Structure):

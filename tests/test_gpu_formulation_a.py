@@ -295,3 +295,41 @@ def test_per_instance_invalid_records_are_flagged(FA):
     # record 0 equals the handle-wide path bit for bit in its counters and to rounding in the solution
     st_b = q_to_dev(st0[:1]); ob = q_from_dev(gen.tick_torch(st_b), FA.OUT_A)
     assert np.abs(ob["u0"][0] - o["u0"][0]).max() <= 1e-9 and np.abs(ob["f0"][0] - o["f0"][0]).max() <= 1e-10
+
+
+@pytest.mark.parametrize("name", ["walk_C100", "walk_C150", "trot_C160"])
+def test_block_warm_start_equals_cold_start(FA, name, monkeypatch):
+    """The block warm start (primal-dual passes before Goldfarb-Idnani) only changes the route, never the optimum: 4 096
+    perturbed instances per workload, pushes from mild to far beyond what the ZMP band can absorb (infeasible QPs
+    included), warm-started handle against a handle created with ISMPC_A_WARM=0."""
+    import torch
+    z = np.load(os.path.join(GOLDEN, f"prerollA_{name}.npz"))
+    tab = z["state"].view(FA.STATE_A).reshape(-1)
+    kind = int(z["gait"]); g = FA.default_gait(kind, float(z["phi"]), float(z["disp_A"]))
+    _, ce = FA.plan(g)
+    p = FA.default_params(kind, C=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
+    monkeypatch.delenv("ISMPC_A_WARM", raising=False)
+    warm = FA.GaitGenerator(p, ce)
+    monkeypatch.setenv("ISMPC_A_WARM", "0")
+    cold = FA.GaitGenerator(p, ce)
+    rng = np.random.default_rng(11)
+    B = 4096
+    st0 = tab[rng.integers(0, len(tab), B)].copy()
+    scale = rng.choice([1.0, 3.0, 10.0, 30.0], B, p=[0.55, 0.25, 0.15, 0.05])
+    push = np.stack([rng.uniform(-0.03, 0.03, B), rng.uniform(-0.05, 0.05, B)], 1) * scale[:, None]
+    d_push = torch.from_numpy(push.copy()).to("cuda:0")
+    sw, sc = q_to_dev(st0), q_to_dev(st0)
+    ow = q_from_dev(warm.tick_torch(sw, d_push), FA.OUT_A)
+    oc = q_from_dev(cold.tick_torch(sc, d_push), FA.OUT_A)
+    torch.cuda.synchronize()
+    inf = FA.ST_X_INFEASIBLE | FA.ST_Y_INFEASIBLE
+    assert ((ow["status"] & ~(inf | FA.ST_UNVERIFIED)) == 0).all() and ((oc["status"] & ~(inf | FA.ST_UNVERIFIED)) == 0).all()
+    assert ((ow["status"] & inf) == (oc["status"] & inf)).all()                    # the same QPs are reported infeasible
+    ok = ow["status"] == 0
+    assert ok.sum() > B // 2 and (~ok).sum() > 0                                   # both kinds are present
+    assert np.abs(ow["u0"][ok] - oc["u0"][ok]).max() <= 1e-7 * max(1.0, np.abs(oc["u0"][ok]).max())
+    assert np.abs(ow["f0"][ok] - oc["f0"][ok]).max() <= 1e-8
+    assert (ow["active"][ok] == oc["active"][ok]).mean() > 0.99                    # same working-set sizes (ties aside)
+    a, b = q_from_dev(sw, FA.STATE_A), q_from_dev(sc, FA.STATE_A)
+    assert (a["fc"] == b["fc"]).all() and (a["j"] == b["j"]).all()
+    assert ow["iters_x"][ok].mean() < 0.6 * oc["iters_x"][ok].mean()               # and it does shorten the route
