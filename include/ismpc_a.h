@@ -113,9 +113,13 @@ int ismpc_a_initial_state(const ismpc_a_handle* h, double disp_C, ismpc_a_state*
  * disturbances added before the QP (quad_walk_no_plots.m:134-148); out may be NULL. */
 int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const double* push_dev,
                               ismpc_a_out* out_dev, void* stream);
-/* `ticks` ticks, out_traj NULL or ticks x batch records. */
+/* `ticks` ticks, out_traj NULL or ticks x batch records.  Inside a rollout every QP starts from the working set the same
+ * instance ended the previous tick with (moved by one sample); the optimum is the same, the route shorter. */
 int ismpc_a_rollout_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, int ticks,
                            ismpc_a_out* out_traj_dev, void* stream);
+/* The same first guess for caller-driven loops of ismpc_a_tick_batch*_device: enable it when instance i of one call is
+ * instance i of the previous one (a wrong guess costs time, never accuracy).  Off by default. */
+int ismpc_a_set_warm_history(ismpc_a_handle* h, int enabled);
 
 /* Per-instance gait parameters (one ismpc_a_inst per instance, device pointer).  The handle fixes C, P, dt, w, the
  * kinematic limits and the maximum F; height, Qf, step, ds, F and the base plan come from inst_dev.  An instance

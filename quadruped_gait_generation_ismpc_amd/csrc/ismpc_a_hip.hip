@@ -667,7 +667,7 @@ template <int RL, int F, bool PI>
 __global__ __launch_bounds__(T, ISMPC_A_WAVE_MINBLOCKS)
 void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
                        const ismpc_a_inst* __restrict__ ipar, const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch,
-                       int* __restrict__ work_counter)
+                       int* __restrict__ work_counter, unsigned long long* __restrict__ hist, int hist_load)
 {
     constexpr int m = 2 * F + 1;
     __shared__ WaveLds<F> lds_all[T / 64];
@@ -859,6 +859,25 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 for (int s_ = 0; s_ < NG; ++s_) { const int e = lane + 64 * s_; gi_[s_] = e / m; gj_[s_] = e - (e / m) * m; }
                 bool cold = false, force_add = false;
                 int peel = 1, extra = c.warm_extra, nsolve = 0;
+                // closed loop: the working set this instance ended the previous tick with, moved down by one row (the
+                // horizon advanced by one sample), is the first guess; any guess is safe, the passes validate it
+                int guess[RL];
+                bool have_guess = false;
+#pragma unroll
+                for (int k = 0; k < RL; ++k) guess[k] = 0;
+                if (hist != nullptr && hist_load) {
+                    const unsigned long long* hq = hist + (size_t)work * 8;
+                    unsigned long long any_ = 0ull;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const unsigned long long lo_ = (k < RL - 1) ? hq[k + 1] : (hq[0] >> 1);          // rows on the lower bound
+                        const unsigned long long hi_ = (k < RL - 1) ? hq[4 + k + 1] : (hq[4] >> 1);      // rows on the upper bound
+                        const int i = lane * RL + k + 1;
+                        if (i <= C) guess[k] = ((lo_ >> lane) & 1ull) ? 1 : (((hi_ >> lane) & 1ull) ? -1 : 0);
+                        any_ |= lo_ | hi_;
+                    }
+                    have_guess = any_ != 0ull;
+                }
                 for (int pass = 0; ; ++pass) {
                     const bool adding = pass < c.warm_add || force_add;
                     force_add = false;
@@ -925,7 +944,8 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                             int ns = sta[k];
                             const double v = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + (1.0 - w1[k]) * L.fl[k1[k] + 1]);
                             aul += ap[i - 1] * u[k];
-                            if (ns != 0) {
+                            if (have_guess && pass == 0) ns = guess[k];
+                            else if (ns != 0) {
                                 // an active row must sit on its bound after the block solve; if it does not, the solve broke down
                                 const double bd = ns > 0 ? zlo[k] : zhi[k];
                                 off_bound = off_bound || !(fabs(v - bd) <= 1e-8 * (fabs(v) + fabs(bd)) + 1e-10);
@@ -1403,6 +1423,14 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 status |= (axis == 0 ? ISMPC_A_ST_X_INFEASIBLE : ISMPC_A_ST_Y_INFEASIBLE) | ISMPC_A_ST_UNVERIFIED;
         }
 
+        if (hist != nullptr) {
+            unsigned long long* hq = hist + (size_t)work * 8;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) {
+                const unsigned long long lo_ = __builtin_amdgcn_ballot_w64(status == 0 && sta[k] > 0), hi_ = __builtin_amdgcn_ballot_w64(status == 0 && sta[k] < 0);
+                if (lane == 0) { hq[k] = lo_; hq[4 + k] = hi_; }
+            }
+        }
         // ---- LIP update (:297-322), footstep bookkeeping (:522-556), outputs
         const bool ok = (status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) == 0;
         const double u0 = ok ? rl_d(u[0], 0) : 0.0;
@@ -1575,6 +1603,9 @@ struct ismpc_a_handle {
     bool use_wave = true; int wave_blocks = 0;           // structured wavefront-per-QP kernel (default) vs workgroup-per-QP
     int cus = 0, wave_occ[2] = {0, 0};                   // resident workgroups per CU of the wave kernel (handle-wide / per-instance parameters)
     int* work_counter = nullptr;
+    unsigned long long* hist = nullptr; int hist_cap = 0;   // per-QP working set of the previous tick (closed-loop first guess)
+    bool hist_ticks = false, hist_valid = false;           // use it in plain tick calls too / it holds the previous tick of this batch
+    int hist_batch = 0; bool hist_off = false;            // ISMPC_A_HISTORY=0: never (A/B)
     std::vector<void*> allocs;
     std::vector<double> fsx, fsy;
 };
@@ -1702,6 +1733,7 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     c.disp_forw = p->disp_forw; c.disp_forw_dummy = p->disp_forw_dummy; c.disp_L = p->disp_L;
     c.ldq = (p->C + p->F + 2) | 1;                        // odd leading dimension: conflict-free LDS columns
     c.max_iter = 20 * (p->C + p->F) + 200;
+    if (const char* e = std::getenv("ISMPC_A_HISTORY")) h->hist_off = std::atoi(e) == 0;
     c.warm_add = 4; c.warm_drop = 6; c.warm_extra = 0;    // ISMPC_A_WARM=add,drop,extra overrides; ISMPC_A_WARM=0 starts every QP cold
     if (const char* e = std::getenv("ISMPC_A_WARM")) {
         int a_ = 0, d_ = 0, x_ = 0;
@@ -1778,6 +1810,7 @@ void ismpc_a_destroy(ismpc_a_handle* h)
     (void)hipSetDevice(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->prev) (void)hipFree(h->prev);
+    if (h->hist) (void)hipFree(h->hist);
     if (h->feet_base) (void)hipFree(h->feet_base);
     delete h;
 }
@@ -1808,12 +1841,28 @@ int ismpc_a_add_plan(ismpc_a_handle* h, const double* center)
 }
 
 static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev, const double* push_dev,
-                       ismpc_a_out* out_dev, void* stream)
+                       ismpc_a_out* out_dev, void* stream, int history = -1)
 {
     if (!h || batch < 0 || (batch > 0 && !state_dev)) return fail_a(-1, "bad argument");
     if (batch == 0) return 0;
     HIP_TRY_A(hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // history: -1 = as set by ismpc_a_set_warm_history, 0 = none, 1 = first tick of a rollout (store only), 2 = load + store
+    if (history < 0) history = h->hist_ticks ? ((h->hist_valid && h->hist_batch == batch) ? 2 : 1) : 0;
+    if (h->c.warm_add <= 0 || h->hist_off) history = 0;
+    unsigned long long* hist = nullptr;
+    if (history > 0) {
+        if (batch > h->hist_cap) {
+            if (h->hist) (void)hipFree(h->hist);
+            h->hist = nullptr; h->hist_cap = 0; h->hist_valid = false;
+            HIP_TRY_A(hipMalloc((void**)&h->hist, sizeof(unsigned long long) * 16 * (size_t)batch));
+            h->hist_cap = batch;
+        }
+        hist = h->hist;
+        if (history == 2 && !(h->hist_valid && h->hist_batch == batch)) history = 1;
+        h->hist_valid = true; h->hist_batch = batch;
+    }
+    const int hist_load = history == 2 ? 1 : 0;
     if (batch > h->prev_cap) {
         if (h->prev) (void)hipFree(h->prev);
         h->prev = nullptr; h->prev_cap = 0;
@@ -1833,7 +1882,7 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
                                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_, T, 0) != hipSuccess || nb < 1) nb = 1; \
                                 h->wave_occ[pi] = nb; } \
                             const int grid = std::min((2 * batch + 3) / 4, h->cus * h->wave_occ[pi]); \
-                            hipLaunchKernelGGL(K_, dim3(grid), dim3(T), 0, s, h->c, prev, state_dev, inst_dev, push_dev, out_dev, batch, h->work_counter); } while (0)
+                            hipLaunchKernelGGL(K_, dim3(grid), dim3(T), 0, s, h->c, prev, state_dev, inst_dev, push_dev, out_dev, batch, h->work_counter, hist, hist_load); } while (0)
 #define ISMPC_A_W(RL_, F_) do { if (inst_dev) ISMPC_A_W1((ismpc_a_tick_wave<RL_, F_, true>)); else ISMPC_A_W1((ismpc_a_tick_wave<RL_, F_, false>)); } while (0)
 #define ISMPC_A_WF(RL_) do { switch (h->c.F) { case 3: ISMPC_A_W(RL_, 3); break; case 4: ISMPC_A_W(RL_, 4); break; \
                                                case 5: ISMPC_A_W(RL_, 5); break; case 6: ISMPC_A_W(RL_, 6); break; default: launched = false; } } while (0)
@@ -1857,6 +1906,13 @@ int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state
     return tick_launch(h, batch, state_dev, nullptr, push_dev, out_dev, stream);
 }
 
+int ismpc_a_set_warm_history(ismpc_a_handle* h, int enabled)
+{
+    if (!h) return fail_a(-1, "null handle");
+    h->hist_ticks = enabled != 0; h->hist_valid = false;
+    return 0;
+}
+
 int ismpc_a_tick_batch_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev,
                                    const double* push_dev, ismpc_a_out* out_dev, void* stream)
 {
@@ -1869,7 +1925,8 @@ int ismpc_a_rollout_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* sta
 {
     if (!h || batch < 0 || ticks < 0) return fail_a(-1, "bad argument");
     for (int t = 0; t < ticks; ++t) {
-        int rc = ismpc_a_tick_batch_inst_device(h, batch, state_dev, inst_dev, nullptr, out_traj_dev ? out_traj_dev + (size_t)t * batch : nullptr, stream);
+        if (batch > 0 && !inst_dev) return fail_a(-1, "null per-instance parameter array");
+        int rc = tick_launch(h, batch, state_dev, inst_dev, nullptr, out_traj_dev ? out_traj_dev + (size_t)t * batch : nullptr, stream, t == 0 ? 1 : 2);
         if (rc) return rc;
     }
     return 0;
@@ -1922,11 +1979,13 @@ int ismpc_a_rollout_feet_device(ismpc_a_handle* h, int batch, ismpc_a_state* sta
                                 double* feet_dev, void* stream)
 {
     if (!h || !out_traj_dev || batch < 0 || ticks < 0) return fail_a(-1, "bad argument");
-    for (int t = 0; t < ticks; ++t) {
-        int rc = ismpc_a_tick_feet_batch_device(h, batch, state_dev, nullptr, out_traj_dev + (size_t)t * batch, feet_dev, stream);
-        if (rc) return rc;
-    }
-    return 0;
+    const bool keep = h->hist_ticks;
+    h->hist_ticks = true; h->hist_valid = false;                     // closed loop: previous working set as the first guess
+    int rc = 0;
+    for (int t = 0; t < ticks && !rc; ++t)
+        rc = ismpc_a_tick_feet_batch_device(h, batch, state_dev, nullptr, out_traj_dev + (size_t)t * batch, feet_dev, stream);
+    h->hist_ticks = keep; h->hist_valid = false;
+    return rc;
 }
 
 // quad_as_bip_no_plots.m:482-509 / quad_walk_no_plots.m:562-613 (host)
@@ -1990,7 +2049,7 @@ int ismpc_a_rollout_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_de
 {
     if (!h || batch < 0 || ticks < 0 || (batch > 0 && !state_dev)) return fail_a(-1, "bad argument");
     for (int t = 0; t < ticks; ++t) {
-        int rc = ismpc_a_tick_batch_device(h, batch, state_dev, nullptr, out_traj_dev ? out_traj_dev + (size_t)t * batch : nullptr, stream);
+        int rc = tick_launch(h, batch, state_dev, nullptr, nullptr, out_traj_dev ? out_traj_dev + (size_t)t * batch : nullptr, stream, t == 0 ? 1 : 2);
         if (rc) return rc;
     }
     return 0;

@@ -37,7 +37,7 @@ EXPORTS_A = ["ismpc_a_params_default", "ismpc_a_gait_default", "ismpc_a_plan", "
              "ismpc_a_initial_state", "ismpc_a_tick_batch_device", "ismpc_a_rollout_device", "ismpc_a_last_error",
              "ismpc_a_feet_rows", "ismpc_a_feet_init_device", "ismpc_a_tick_feet_batch_device",
              "ismpc_a_rollout_feet_device", "ismpc_a_foot_trajectories", "ismpc_a_write_trajectory_txt",
-             "ismpc_a_add_plan", "ismpc_a_tick_batch_inst_device", "ismpc_a_rollout_inst_device"]
+             "ismpc_a_add_plan", "ismpc_a_tick_batch_inst_device", "ismpc_a_rollout_inst_device", "ismpc_a_set_warm_history"]
 FEET_PAD = 8
 
 _bound = False
@@ -63,6 +63,7 @@ def _l():
         lib.ismpc_a_rollout_feet_device.argtypes = [vp, ci, vp, ci, vp, vp, vp]; lib.ismpc_a_rollout_feet_device.restype = ci
         lib.ismpc_a_foot_trajectories.argtypes = [C.POINTER(GaitA), ci, vp, ci, ci, vp]; lib.ismpc_a_foot_trajectories.restype = ci
         lib.ismpc_a_write_trajectory_txt.argtypes = [C.c_char_p, vp, ci]; lib.ismpc_a_write_trajectory_txt.restype = ci
+        lib.ismpc_a_set_warm_history.argtypes = [vp, ci]; lib.ismpc_a_set_warm_history.restype = ci
         lib.ismpc_a_add_plan.argtypes = [vp, vp]; lib.ismpc_a_add_plan.restype = ci
         lib.ismpc_a_tick_batch_inst_device.argtypes = [vp, ci, vp, vp, vp, vp, vp]; lib.ismpc_a_tick_batch_inst_device.restype = ci
         lib.ismpc_a_rollout_inst_device.argtypes = [vp, ci, vp, vp, ci, vp, vp]; lib.ismpc_a_rollout_inst_device.restype = ci
@@ -186,6 +187,11 @@ class GaitGenerator:
         if rc != 0:
             raise IsmpcAError(_l().ismpc_a_last_error().decode())
         return traj
+
+    def set_warm_history(self, enabled=True):
+        """Caller-driven tick loops: start every QP from the working set the same instance had in the previous call."""
+        if _l().ismpc_a_set_warm_history(self._h, 1 if enabled else 0) != 0:
+            raise IsmpcAError(_l().ismpc_a_last_error().decode())
 
     # per-instance gait parameters (INST_A records): Monte-Carlo / sweep batches
     def add_plan(self, center):

@@ -54,6 +54,17 @@ push = np.stack([rng.uniform(-0.03, 0.03, batch), rng.uniform(-0.05, 0.05, batch
 d0 = q.to_device(st0); d = d0.clone(); dpush = torch.from_numpy(push.copy()).cuda()
 out = gen.tick_torch(d, dpush); torch.cuda.synchronize()
 o = q.from_device(out, FA.OUT_A)
+if "--rollout" in sys.argv:
+    # closed loop: one pushed tick, then T ticks on the device (Monte-Carlo robustness use: the previous working set is the first guess)
+    T = int(sys.argv[sys.argv.index("--rollout") + 1])
+    gen.rollout_torch(d, 3); torch.cuda.synchronize()
+    d.copy_(d0); gen.tick_torch(d, dpush)
+    t0 = time.perf_counter(); traj = gen.rollout_torch(d, T); torch.cuda.synchronize(); el = time.perf_counter() - t0
+    tr = q.from_device(traj, FA.OUT_A)
+    print(json.dumps({"workload": name + " rollout", "batch": batch, "ticks": T, "ticks_per_s": batch * T / el, "ms_per_tick": 1e3 * el / T,
+                      "status_nonzero": int((tr["status"] != 0).sum()), "iters_mean": float((tr["iters_x"] + tr["iters_y"]).mean() / 2),
+                      "active_mean": float(((tr["active"] & 0xffff) + (tr["active"] >> 16)).mean() / 2)}))
+    sys.exit(0)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0 = time.perf_counter(); e0.record()
 for _ in range(steps):
