@@ -693,6 +693,9 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
         const int work = __builtin_amdgcn_readfirstlane(claimed);
         if (work >= 2 * batch) break;
         const int inst = work >> 1, axis = work & 1;
+#ifdef ISMPC_A_PROF
+        unsigned long long pq_ = __builtin_readcyclecounter();
+#endif
         const ismpc_a_state st = state_in[inst];
         const double pos = axis == 0 ? st.x : st.y;
         const double vel = (axis == 0 ? st.xd : st.yd) + (push ? push[inst * 2 + axis] : 0.0);
@@ -711,7 +714,8 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 status |= ISMPC_A_ST_BAD_INDEX; step_ = 2; ds_ = 1; Fi = 1; plan = 0; Qf = 1.0; eta = 1.0;
             } else eta = sqrt(c.grav / ip.height);
         }
-        const double sq = sqrt(Qf), isq = 1.0 / sq;
+        const double sq = sqrt(Qf), isq = 1.0 / sq, iQf = 1.0 / Qf;
+        const float rstep = 1.0f / (float)step_;
         const double* fs = PI ? (axis == 0 ? c.plan_x[plan] : c.plan_y[plan]) : (axis == 0 ? c.fsx : c.fsy);
         const double* cl = st.rebuilt ? (axis == 0 ? c.clx1 : c.cly1) : (axis == 0 ? c.clx0 : c.cly0);
         const double cloff = st.rebuilt ? off : 0.0;
@@ -748,7 +752,9 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
             const int i = lane * RL + k + 1;
             u[k] = 0.0; mu[k] = 0.0; sta[k] = 0; prv[k] = 0; nxt[k] = 0;
             if (i <= C) {
-                int pf = (j + i) / step_ - fc + 1; if (pf < 0) pf = 0;
+                int qd = (int)((float)(j + i) * rstep);                          // (j + i) / step_ without the integer-division sequence
+                if (qd * step_ > j + i) --qd; else if ((qd + 1) * step_ <= j + i) ++qd;
+                int pf = qd - fc + 1; if (pf < 0) pf = 0;
                 const int rem = step_ * (fc + pf) - (j + i);
                 w1[k] = (rem > ds_) ? 1.0 : (double)rem / ds_;                    // mapping(i, pf+1); the next column gets 1 - w1
                 k1[k] = pf;
@@ -758,7 +764,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 const double w2 = 1.0 - w1[k];
                 double mm = w2 * w2;                                              // |M_i|^2 over the footstep columns
                 if (pf >= 1) mm += w1[k] * w1[k];
-                inrm[k] = 1.0 / sqrt(dt * dt * (double)i + mm / Qf);
+                { const double xn = dt * dt * (double)i + mm * iQf; double r_ = __builtin_amdgcn_rsq(xn); inrm[k] = r_ * (1.5 - 0.5 * xn * r_ * r_); }   // only ranks candidates
                 L.k1s[i - 1] = pf; L.w1s[i - 1] = w1[k];
             } else { w1[k] = 1.0; k1[k] = 0; zlo[k] = -INFINITY; zhi[k] = INFINITY; inrm[k] = 0.0; }
         }
@@ -794,6 +800,10 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
         const double knrm = (lane >= 2) ? sq * 0.70710678118654752440 : sq;   // 1 / |K_r|_{H^-1}: |kvec_r|^2 = 2 (r >= 2) or 1
         int iters = 0, qz = 0, qk = 0;
         double muE = 0.0;
+        bool done_opt = false;                                // the block passes ended on a checked optimum: nothing left to do
+#ifdef ISMPC_A_PROF
+        { const unsigned long long n_ = __builtin_readcyclecounter(); if (lane == 0 && (work & 127) == 0) { atomicAdd(&g_prof[10], n_ - pq_); atomicAdd(&g_prof[26], 1ull); } pq_ = n_; }
+#endif
         if (status == 0) {
             // ---- equality first: u = (b / a'a) a
             const double t0 = beq / aa;
@@ -966,6 +976,18 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                     }
                     if (__builtin_amdgcn_ballot_w64(changed) == 0) {               // a valid pair (and, while adding, nothing violated)
                         if (!adding && extra > 0) { --extra; force_add = true; continue; }   // valid after drop-only passes: one more adding pass
+                        if (adding && nsolve > 0) {
+                            // every ZMP row was just evaluated at this point (none violated, active ones on their bounds, the
+                            // stability row holds, multipliers positive); with the kinematic rows inside their limits this
+                            // IS the optimum: skip the Goldfarb-Idnani search and the final re-check
+                            const double fprev = dpp64<0x111, 0xf, true>(0.0, fr);
+                            bool kbad = false;
+                            if (klane && khi < INFINITY) {
+                                const double vk = fr - fprev, tol = 1e-11 * (fabs(vk) + fmax(fabs(klo), fabs(khi))) + 1e-13;
+                                kbad = !(vk - klo >= -tol && khi - vk >= -tol);
+                            }
+                            done_opt = __builtin_amdgcn_ballot_w64(kbad) == 0;
+                        }
                         break;
                     }
                     if (nsolve >= c.warm_add + c.warm_drop + c.warm_extra * (1 + c.warm_drop)) { cold = true; break; }   // budget spent: start cold
@@ -1127,7 +1149,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 }
             }
 
-            for (;;) {
+            if (!done_opt) for (;;) {
                 PROF_T0();
                 // ================= most violated inactive row =================
                 if (lane <= F + 1) L.fl[lane] = fr;
@@ -1391,11 +1413,14 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
             }
         }
 
+#ifdef ISMPC_A_PROF
+        { const unsigned long long n_ = __builtin_readcyclecounter(); if (lane == 0 && (work & 127) == 0) { atomicAdd(&g_prof[11], n_ - pq_); atomicAdd(&g_prof[27], 1ull); } pq_ = n_; }
+#endif
         // ---- every row, active or not, the kinematic rows and the stability row are checked once more at the point that
         // is about to be returned: a working set that pins (nearly) every variable of an infeasible QP can break the small
         // solves down without any inactive row showing it.  Such a QP is reported infeasible (the reference's quadprog
         // returns no solution there).
-        if (status == 0) {
+        if (status == 0 && !done_opt) {
             if (lane <= F + 1) L.fl[lane] = fr;
             WAVE_LDS_SYNC();
             double lc = 0.0, cm[RL], aul = 0.0;
@@ -1467,6 +1492,9 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
             }
         }
         WAVE_LDS_SYNC();
+#ifdef ISMPC_A_PROF
+        { const unsigned long long n_ = __builtin_readcyclecounter(); if (lane == 0 && (work & 127) == 0) { atomicAdd(&g_prof[12], n_ - pq_); atomicAdd(&g_prof[28], 1ull); } }
+#endif
     }
 }
 
