@@ -8,7 +8,7 @@ import csv, glob, json, os, sys
 root, kern, out = sys.argv[1], sys.argv[2], sys.argv[3]
 extra = dict(a.split("=", 1) for a in sys.argv[4:])
 sums, cnts, launches = {}, {}, {}
-for f in sorted(glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")) + glob.glob(os.path.join(root, "*counter_collection.csv"))):
+for f in sorted(glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")) + glob.glob(os.path.join(root, "*", "*counter_collection.csv")) + glob.glob(os.path.join(root, "*counter_collection.csv"))):
     with open(f, newline="") as fh:
         for row in csv.DictReader(fh):
             if kern not in row["Kernel_Name"]:
