@@ -854,6 +854,167 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 return cc_e;
             };
 
+            constexpr int NG = (m * m + 63) / 64;
+            int gi_[NG], gj_[NG];
+#pragma unroll
+            for (int s_ = 0; s_ < NG; ++s_) { const int e = lane + 64 * s_; gi_[s_] = e / m; gj_[s_] = e - (e / m) * m; }
+            // ---- one structured solve for a whole working set (the ZMP rows in sta[], the kinematic rows in kmask / kact):
+            // minimiser u, f and all multipliers; leaves G(W) in L.G and prv / nxt of every row
+            auto block_solve = [&](const unsigned long long kmask) __attribute__((always_inline)) {
+                // ---- previous / next active row of every row (active or not): exclusive max scan, exclusive suffix min scan
+                int nact = 0;
+                double cvr[RL];
+                // active kinematic rows: right-hand sides sqrt(Qf) (bound_r - (p_r - p_{r-1})) travel to the lanes of their unknowns
+                if (klane) L.d1[lane - 1] = (kact != 0) ? sq * ((kact > 0 ? klo : khi) - (L.pf[lane] - L.pf[lane - 1])) : 0.0;
+                {
+                    int lmax = 0, lmin = 1 << 30;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        const bool act = i <= C && sta[k] != 0;
+                        if (act) { lmax = max(lmax, i); lmin = min(lmin, i); }
+                        nact += __builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
+                        // c_i = bound_i + M_i . plan footsteps
+                        cvr[k] = act ? (sta[k] > 0 ? zlo[k] : zhi[k]) + (w1[k] * L.pf[k1[k]] + (1.0 - w1[k]) * L.pf[k1[k] + 1]) : 0.0;
+                        if (i <= C) L.sv[i - 1] = cvr[k];                    // c of every row, for its successor
+                    }
+                    int run = dpp_i<0x138, 0xf>(0, wave_scan_max_i(lmax));
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; prv[k] = run; if (i <= C && sta[k] != 0) run = i; }
+                    const int rev = __shfl(lmin, 63 - lane);
+                    const int ex = dpp_i<0x138, 0xf>(1 << 30, -wave_scan_max_i(-rev));
+                    const int nx = __shfl(ex, 63 - lane);
+                    run = (nx == (1 << 30)) ? 0 : nx;
+#pragma unroll
+                    for (int k = RL - 1; k >= 0; --k) { const int i = lane * RL + k + 1; nxt[k] = run; if (i <= C && sta[k] != 0) run = i; }
+                }
+                WAVE_LDS_SYNC();
+                // ---- G = V'K^-1 V / dt^2 and g = V'K^-1 c / dt^2 as sums over consecutive active pairs (p, i) of
+                // d d' / gap, d = V_i - V_p.  V_i = Phi(theta_i) + dt PA_i e_E with theta_i the row's mapping weights over the
+                // F footstep columns and Phi a fixed sparse map, so everything follows from the Gram sums of
+                // [dtheta (F) | dt dPA | dc] weighted by 1 / (dt^2 gap): each lane adds its own rows, one reduction per entry.
+                {
+                    constexpr int NT = F * (F + 1) / 2, NS = NT + 2 * F + 2;
+                    double acc[NS];
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) acc[t] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        if (i <= C && sta[k] != 0) {
+                            const int p_ = prv[k];
+                            int pk1 = -8; double pw1 = 0.0, ppa = 0.0, pc = 0.0;               // V_0 = 0, c_0 = 0
+                            if (p_ > 0) { pk1 = L.k1s[p_ - 1]; pw1 = L.w1s[p_ - 1]; ppa = pap[p_]; pc = L.sv[p_ - 1]; }
+                            const double pw2 = (p_ > 0) ? 1.0 - pw1 : 0.0, w2 = 1.0 - w1[k];
+                            const double om = idt2 * frcp((double)(i - p_));
+                            const double dE = dt * (pap[i] - ppa), dc = cvr[k] - pc;
+                            double dth[F];
+#pragma unroll
+                            for (int r = 1; r <= F; ++r) {
+                                const double ti = (r == k1[k]) ? w1[k] : ((r == k1[k] + 1) ? w2 : 0.0);
+                                const double tp = (r == pk1) ? pw1 : ((r == pk1 + 1) ? pw2 : 0.0);
+                                dth[r - 1] = ti - tp;
+                            }
+                            int t = 0;
+#pragma unroll
+                            for (int r = 0; r < F; ++r) {
+                                const double od = om * dth[r];
+#pragma unroll
+                                for (int q = r; q < F; ++q) acc[t++] += od * dth[q];
+                                acc[NT + r] += od * dE; acc[NT + F + r] += od * dc;
+                            }
+                            acc[NT + 2 * F] += om * dE * dE; acc[NT + 2 * F + 1] += om * dE * dc;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) { const double v = wave_sum_d(acc[t]); if (lane == 0) L.th[t] = v; }
+                    WAVE_LDS_SYNC();
+                    // Phi(e): e < F -> +col e+1 ; e > F -> -col (e-F) + col (e-F-1) [if >= 1] ; all scaled by 1/sqrt(Qf)
+                    auto TH = [&](int r, int q) -> double {                       // Theta(r, q), 1-based, symmetric
+                        const int lo_ = min(r, q), hi_ = max(r, q);
+                        return L.th[(lo_ - 1) * F - ((lo_ - 1) * (lo_ - 2)) / 2 + (hi_ - lo_)];
+                    };
+#pragma unroll
+                    for (int s_ = 0; s_ < NG; ++s_) {
+                        const int e = lane + 64 * s_;
+                        if (e < m * m) {
+                            const int i_ = gi_[s_], j_ = gj_[s_];
+                            const int ra = i_ < F ? i_ + 1 : i_ - F, rb = j_ < F ? j_ + 1 : j_ - F;     // leading column of Phi(e)
+                            const double sa = i_ < F ? 1.0 : -1.0, sb = j_ < F ? 1.0 : -1.0;
+                            const bool a2 = i_ > F && ra >= 2, b2 = j_ > F && rb >= 2;                   // second term: +col (r-1)
+                            double val;
+                            if (i_ == F && j_ == F) val = L.th[NT + 2 * F];
+                            else if (i_ == F || j_ == F) {
+                                const int r_ = (i_ == F) ? rb : ra; const double s1 = (i_ == F) ? sb : sa; const bool t2 = (i_ == F) ? b2 : a2;
+                                val = s1 * L.th[NT + r_ - 1];
+                                if (t2) val += L.th[NT + r_ - 2];
+                                val *= isq;
+                            } else {
+                                val = sa * sb * TH(ra, rb);
+                                if (a2) val += sb * TH(ra - 1, rb);
+                                if (b2) val += sa * TH(ra, rb - 1);
+                                if (a2 && b2) val += TH(ra - 1, rb - 1);
+                                val *= isq * isq;
+                            }
+                            L.G[e] = val;
+                        }
+                    }
+                    if (lane < m) {
+                        double gv;
+                        if (lane == F) gv = L.th[NT + 2 * F + 1] - beq;
+                        else {
+                            const int ra = lane < F ? lane + 1 : lane - F;
+                            gv = (lane < F ? 1.0 : -1.0) * L.th[NT + F + ra - 1];
+                            if (lane > F && ra >= 2) gv += L.th[NT + F + ra - 2];
+                            gv *= isq;
+                        }
+                        if (lane > F) gv -= L.d1[lane - F - 1];
+                        L.hx[lane] = gv;
+                    }
+                }
+                WAVE_LDS_SYNC();
+                (void)solve_small(kmask);
+                const double cEw = L.cc[F];
+                // comb[r] = (cc[r-1] - ck[r] + ck[r+1]) / sqrt(Qf), r = 1..F: what a row sees through its two footstep columns
+                // (ck = the kinematic unknowns, 0 where pinned)
+                if (lane <= F + 1) L.comb[lane] = klane ? (L.cc[lane - 1] - L.cc[F + lane] + (lane + 1 <= F ? L.cc[F + lane + 1] : 0.0)) * isq : 0.0;
+                if (klane) muK = (kact != 0) ? (kact > 0 ? 1.0 : -1.0) * L.cc[F + lane] : 0.0;
+                WAVE_LDS_SYNC();
+                double sl[RL];                                               // s_i = c_i - V_i . cc on the active rows
+#pragma unroll
+                for (int k = 0; k < RL; ++k) {
+                    const int i = lane * RL + k + 1;
+                    sl[k] = 0.0;
+                    if (i <= C && sta[k] != 0)
+                        sl[k] = cvr[k] - (w1[k] * L.comb[k1[k]] + (1.0 - w1[k]) * L.comb[k1[k] + 1]) - dt * pap[i] * cEw;
+                    if (i <= C) L.sv[i - 1] = sl[k];
+                }
+                WAVE_LDS_SYNC();
+                // multipliers (tridiagonal K^-1), u = dt suffix(lambda) + lambda_E a, f = plan - comb
+                double ls = 0.0, suf[RL];
+#pragma unroll
+                for (int k = RL - 1; k >= 0; --k) {
+                    const int i = lane * RL + k + 1;
+                    double r_ = 0.0;
+                    if (i <= C && sta[k] != 0) {
+                        const double sp = prv[k] > 0 ? L.sv[prv[k] - 1] : 0.0;
+                        r_ = (sl[k] - sp) * frcp((double)(i - prv[k]));
+                        if (nxt[k] > 0) r_ -= (L.sv[nxt[k] - 1] - sl[k]) * frcp((double)(nxt[k] - i));
+                        r_ *= idt2;
+                    }
+                    mu[k] = sta[k] > 0 ? r_ : -r_;
+                    ls += dt * r_; suf[k] = ls;
+                }
+                const double incl = wave_scan_up(ls);
+                const double above = rl_d(incl, 63) - incl;
+#pragma unroll
+                for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; u[k] = (i <= C) ? (suf[k] + above) + cEw * ap[i - 1] : 0.0; }
+                if (klane) fr = L.pf[lane] - L.comb[lane];
+                muE = cEw;
+                qz = nact;
+                WAVE_LDS_SYNC();
+            };
+
             // ================= block warm start (primal-dual active-set passes) =================
             // The loop below adds one row per iteration and a nominal tick ends with 40-70 active rows.  Before it, up to
             // c.warm_add passes put every violated ZMP row into the working set at once (and take out rows whose multiplier
@@ -863,10 +1024,6 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
             // valid starting pair for Goldfarb-Idnani (minimiser on its working set, multipliers >= 0), which finishes the
             // job and owns the kinematic rows; if the passes do not get there the solve starts cold.  Same optimum either way.
             if (c.warm_add > 0) {
-                constexpr int NG = (m * m + 63) / 64;
-                int gi_[NG], gj_[NG];
-#pragma unroll
-                for (int s_ = 0; s_ < NG; ++s_) { const int e = lane + 64 * s_; gi_[s_] = e / m; gj_[s_] = e - (e / m) * m; }
                 bool cold = false, force_add = false;
                 int peel = 1, extra = c.warm_extra, nsolve = 0;
                 // closed loop: the working set this instance ended the previous tick with, moved down by one row (the
@@ -945,11 +1102,10 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                     }
                     peel = wave_neg ? min(2 * peel, 64) : 1;
                     bool changed = false, off_bound = false;
-                    double cvr[RL], aul = 0.0;
+                    double aul = 0.0;
 #pragma unroll
                     for (int k = 0; k < RL; ++k) {
                         const int i = lane * RL + k + 1;
-                        cvr[k] = 0.0;
                         if (i <= C) {
                             int ns = sta[k];
                             const double v = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + (1.0 - w1[k]) * L.fl[k1[k] + 1]);
@@ -966,8 +1122,6 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                             }
                             changed = changed || ns != sta[k];
                             sta[k] = ns;
-                            // c_i = bound_i + M_i . plan footsteps
-                            if (ns != 0) cvr[k] = (ns > 0 ? zlo[k] : zhi[k]) + (w1[k] * L.pf[k1[k]] + (1.0 - w1[k]) * L.pf[k1[k] + 1]);
                         }
                     }
                     if (nsolve > 0) {
@@ -992,150 +1146,7 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                     }
                     if (nsolve >= c.warm_add + c.warm_drop + c.warm_extra * (1 + c.warm_drop)) { cold = true; break; }   // budget spent: start cold
                     ++nsolve; ++iters;
-                    // ---- previous / next active row of every row (active or not): exclusive max scan, exclusive suffix min scan
-                    int nact = 0;
-                    {
-                        int lmax = 0, lmin = 1 << 30;
-#pragma unroll
-                        for (int k = 0; k < RL; ++k) {
-                            const int i = lane * RL + k + 1;
-                            const bool act = i <= C && sta[k] != 0;
-                            if (act) { lmax = max(lmax, i); lmin = min(lmin, i); }
-                            nact += __builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
-                            if (i <= C) L.sv[i - 1] = cvr[k];                    // c of every row, for its successor
-                        }
-                        int run = dpp_i<0x138, 0xf>(0, wave_scan_max_i(lmax));
-#pragma unroll
-                        for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; prv[k] = run; if (i <= C && sta[k] != 0) run = i; }
-                        const int rev = __shfl(lmin, 63 - lane);
-                        const int ex = dpp_i<0x138, 0xf>(1 << 30, -wave_scan_max_i(-rev));
-                        const int nx = __shfl(ex, 63 - lane);
-                        run = (nx == (1 << 30)) ? 0 : nx;
-#pragma unroll
-                        for (int k = RL - 1; k >= 0; --k) { const int i = lane * RL + k + 1; nxt[k] = run; if (i <= C && sta[k] != 0) run = i; }
-                    }
-                    WAVE_LDS_SYNC();
-                    // ---- G = V'K^-1 V / dt^2 and g = V'K^-1 c / dt^2 as sums over consecutive active pairs (p, i) of
-                    // d d' / gap, d = V_i - V_p.  V_i = Phi(theta_i) + dt PA_i e_E with theta_i the row's mapping weights over the
-                    // F footstep columns and Phi a fixed sparse map, so everything follows from the Gram sums of
-                    // [dtheta (F) | dt dPA | dc] weighted by 1 / (dt^2 gap): each lane adds its own rows, one reduction per entry.
-                    {
-                        constexpr int NT = F * (F + 1) / 2, NS = NT + 2 * F + 2;
-                        double acc[NS];
-#pragma unroll
-                        for (int t = 0; t < NS; ++t) acc[t] = 0.0;
-#pragma unroll
-                        for (int k = 0; k < RL; ++k) {
-                            const int i = lane * RL + k + 1;
-                            if (i <= C && sta[k] != 0) {
-                                const int p_ = prv[k];
-                                int pk1 = -8; double pw1 = 0.0, ppa = 0.0, pc = 0.0;               // V_0 = 0, c_0 = 0
-                                if (p_ > 0) { pk1 = L.k1s[p_ - 1]; pw1 = L.w1s[p_ - 1]; ppa = pap[p_]; pc = L.sv[p_ - 1]; }
-                                const double pw2 = (p_ > 0) ? 1.0 - pw1 : 0.0, w2 = 1.0 - w1[k];
-                                const double om = idt2 * frcp((double)(i - p_));
-                                const double dE = dt * (pap[i] - ppa), dc = cvr[k] - pc;
-                                double dth[F];
-#pragma unroll
-                                for (int r = 1; r <= F; ++r) {
-                                    const double ti = (r == k1[k]) ? w1[k] : ((r == k1[k] + 1) ? w2 : 0.0);
-                                    const double tp = (r == pk1) ? pw1 : ((r == pk1 + 1) ? pw2 : 0.0);
-                                    dth[r - 1] = ti - tp;
-                                }
-                                int t = 0;
-#pragma unroll
-                                for (int r = 0; r < F; ++r) {
-                                    const double od = om * dth[r];
-#pragma unroll
-                                    for (int q = r; q < F; ++q) acc[t++] += od * dth[q];
-                                    acc[NT + r] += od * dE; acc[NT + F + r] += od * dc;
-                                }
-                                acc[NT + 2 * F] += om * dE * dE; acc[NT + 2 * F + 1] += om * dE * dc;
-                            }
-                        }
-#pragma unroll
-                        for (int t = 0; t < NS; ++t) { const double v = wave_sum_d(acc[t]); if (lane == 0) L.th[t] = v; }
-                        WAVE_LDS_SYNC();
-                        // Phi(e): e < F -> +col e+1 ; e > F -> -col (e-F) + col (e-F-1) [if >= 1] ; all scaled by 1/sqrt(Qf)
-                        auto TH = [&](int r, int q) -> double {                       // Theta(r, q), 1-based, symmetric
-                            const int lo_ = min(r, q), hi_ = max(r, q);
-                            return L.th[(lo_ - 1) * F - ((lo_ - 1) * (lo_ - 2)) / 2 + (hi_ - lo_)];
-                        };
-#pragma unroll
-                        for (int s_ = 0; s_ < NG; ++s_) {
-                            const int e = lane + 64 * s_;
-                            if (e < m * m) {
-                                const int i_ = gi_[s_], j_ = gj_[s_];
-                                const int ra = i_ < F ? i_ + 1 : i_ - F, rb = j_ < F ? j_ + 1 : j_ - F;     // leading column of Phi(e)
-                                const double sa = i_ < F ? 1.0 : -1.0, sb = j_ < F ? 1.0 : -1.0;
-                                const bool a2 = i_ > F && ra >= 2, b2 = j_ > F && rb >= 2;                   // second term: +col (r-1)
-                                double val;
-                                if (i_ == F && j_ == F) val = L.th[NT + 2 * F];
-                                else if (i_ == F || j_ == F) {
-                                    const int r_ = (i_ == F) ? rb : ra; const double s1 = (i_ == F) ? sb : sa; const bool t2 = (i_ == F) ? b2 : a2;
-                                    val = s1 * L.th[NT + r_ - 1];
-                                    if (t2) val += L.th[NT + r_ - 2];
-                                    val *= isq;
-                                } else {
-                                    val = sa * sb * TH(ra, rb);
-                                    if (a2) val += sb * TH(ra - 1, rb);
-                                    if (b2) val += sa * TH(ra, rb - 1);
-                                    if (a2 && b2) val += TH(ra - 1, rb - 1);
-                                    val *= isq * isq;
-                                }
-                                L.G[e] = val;
-                            }
-                        }
-                        if (lane < m) {
-                            double gv;
-                            if (lane == F) gv = L.th[NT + 2 * F + 1] - beq;
-                            else {
-                                const int ra = lane < F ? lane + 1 : lane - F;
-                                gv = (lane < F ? 1.0 : -1.0) * L.th[NT + F + ra - 1];
-                                if (lane > F && ra >= 2) gv += L.th[NT + F + ra - 2];
-                                gv *= isq;
-                            }
-                            L.hx[lane] = gv;
-                        }
-                    }
-                    WAVE_LDS_SYNC();
-                    (void)solve_small(0ull);                                     // kinematic rows stay out of the block phase
-                    const double cEw = L.cc[F];
-                    // comb[r] = cc[r-1] / sqrt(Qf), r = 1..F: what a row sees through its two footstep columns
-                    if (lane <= F + 1) L.comb[lane] = klane ? L.cc[lane - 1] * isq : 0.0;
-                    WAVE_LDS_SYNC();
-                    double sl[RL];                                               // s_i = c_i - V_i . cc on the active rows
-#pragma unroll
-                    for (int k = 0; k < RL; ++k) {
-                        const int i = lane * RL + k + 1;
-                        sl[k] = 0.0;
-                        if (i <= C && sta[k] != 0)
-                            sl[k] = cvr[k] - (w1[k] * L.comb[k1[k]] + (1.0 - w1[k]) * L.comb[k1[k] + 1]) - dt * pap[i] * cEw;
-                        if (i <= C) L.sv[i - 1] = sl[k];
-                    }
-                    WAVE_LDS_SYNC();
-                    // multipliers (tridiagonal K^-1), u = dt suffix(lambda) + lambda_E a, f = plan - comb
-                    double ls = 0.0, suf[RL];
-#pragma unroll
-                    for (int k = RL - 1; k >= 0; --k) {
-                        const int i = lane * RL + k + 1;
-                        double r_ = 0.0;
-                        if (i <= C && sta[k] != 0) {
-                            const double sp = prv[k] > 0 ? L.sv[prv[k] - 1] : 0.0;
-                            r_ = (sl[k] - sp) * frcp((double)(i - prv[k]));
-                            if (nxt[k] > 0) r_ -= (L.sv[nxt[k] - 1] - sl[k]) * frcp((double)(nxt[k] - i));
-                            r_ *= idt2;
-                        }
-                        mu[k] = sta[k] > 0 ? r_ : -r_;
-                        ls += dt * r_; suf[k] = ls;
-                    }
-                    const double incl = wave_scan_up(ls);
-                    const double above = rl_d(incl, 63) - incl;
-#pragma unroll
-                    for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; u[k] = (i <= C) ? (suf[k] + above) + cEw * ap[i - 1] : 0.0; }
-                    if (klane) fr = L.pf[lane] - L.comb[lane];
-                    muE = cEw;
-                    qz = nact;
-                    WAVE_LDS_SYNC();
+                    block_solve(0ull);                                           // kinematic rows stay out of the block phase
                     PROF(8);
                 }
                 if (cold) {
@@ -1411,43 +1422,59 @@ void ismpc_a_tick_wave(const DevA c, const ismpc_a_state* __restrict__ state_in,
                 }
                 if (failed) break;
             }
+            // ---- every row, active or not, the kinematic rows and the stability row are checked once more at the point that
+            // is about to be returned: a working set that pins (nearly) every variable can wear the incremental solves down
+            // without any inactive row showing it.  One block solve of the final working set (kinematic rows included)
+            // polishes such a point; if it still fails, the QP is reported infeasible (the reference's quadprog returns no
+            // solution on infeasible QPs).
+            if (status == 0 && !done_opt) {
+                auto off_point = [&]() __attribute__((always_inline)) -> bool {
+                    if (lane <= F + 1) L.fl[lane] = fr;
+                    WAVE_LDS_SYNC();
+                    double lc = 0.0, cm[RL], aul = 0.0;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) { lc += u[k]; cm[k] = lc; }
+                    const double bs = wave_scan_up(lc) - lc;
+                    bool bad = false;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        if (i <= C) {
+                            const double v = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + (1.0 - w1[k]) * L.fl[k1[k] + 1]);
+                            const double tol = 1e-7 * (fabs(v) + fmax(fabs(zlo[k]), fabs(zhi[k]))) + 1e-9;
+                            bad = bad || !(v - zlo[k] >= -tol && zhi[k] - v >= -tol);
+                            aul += ap[i - 1] * u[k];
+                        }
+                    }
+                    const double fprev = dpp64<0x111, 0xf, true>(0.0, fr);
+                    if (klane && khi < INFINITY) {
+                        const double v = fr - fprev, tol = 1e-7 * (fabs(v) + fmax(fabs(klo), fabs(khi))) + 1e-9;
+                        bad = bad || !(v - klo >= -tol && khi - v >= -tol);
+                    }
+                    const double eqr = wave_sum_d(aul) - beq;
+                    WAVE_LDS_SYNC();
+                    return __builtin_amdgcn_ballot_w64(bad) != 0 || !(fabs(eqr) <= 1e-7 * (1.0 + fabs(beq)));
+                };
+                bool bad = off_point();
+                if (bad && c.warm_add > 0) {
+                    ++iters;
+                    block_solve(__builtin_amdgcn_ballot_w64(klane && kact != 0));
+                    double mmax = fabs(muK);
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) mmax = fmax(mmax, fabs(mu[k]));
+                    const double mtol = 1e-8 * (1.0 - wave_min_d(-mmax));
+                    bool negm = klane && kact != 0 && muK < -mtol;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) negm = negm || (sta[k] != 0 && mu[k] < -mtol);
+                    bad = __builtin_amdgcn_ballot_w64(negm) != 0 || off_point();
+                }
+                if (bad) status |= (axis == 0 ? ISMPC_A_ST_X_INFEASIBLE : ISMPC_A_ST_Y_INFEASIBLE) | ISMPC_A_ST_UNVERIFIED;
+            }
         }
 
 #ifdef ISMPC_A_PROF
         { const unsigned long long n_ = __builtin_readcyclecounter(); if (lane == 0 && (work & 127) == 0) { atomicAdd(&g_prof[11], n_ - pq_); atomicAdd(&g_prof[27], 1ull); } pq_ = n_; }
 #endif
-        // ---- every row, active or not, the kinematic rows and the stability row are checked once more at the point that
-        // is about to be returned: a working set that pins (nearly) every variable of an infeasible QP can break the small
-        // solves down without any inactive row showing it.  Such a QP is reported infeasible (the reference's quadprog
-        // returns no solution there).
-        if (status == 0 && !done_opt) {
-            if (lane <= F + 1) L.fl[lane] = fr;
-            WAVE_LDS_SYNC();
-            double lc = 0.0, cm[RL], aul = 0.0;
-#pragma unroll
-            for (int k = 0; k < RL; ++k) { lc += u[k]; cm[k] = lc; }
-            const double bs = wave_scan_up(lc) - lc;
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < RL; ++k) {
-                const int i = lane * RL + k + 1;
-                if (i <= C) {
-                    const double v = dt * (cm[k] + bs) - (w1[k] * L.fl[k1[k]] + (1.0 - w1[k]) * L.fl[k1[k] + 1]);
-                    const double tol = 1e-7 * (fabs(v) + fmax(fabs(zlo[k]), fabs(zhi[k]))) + 1e-9;
-                    bad = bad || !(v - zlo[k] >= -tol && zhi[k] - v >= -tol);
-                    aul += ap[i - 1] * u[k];
-                }
-            }
-            const double fprev = dpp64<0x111, 0xf, true>(0.0, fr);
-            if (klane && khi < INFINITY) {
-                const double v = fr - fprev, tol = 1e-7 * (fabs(v) + fmax(fabs(klo), fabs(khi))) + 1e-9;
-                bad = bad || !(v - klo >= -tol && khi - v >= -tol);
-            }
-            const double eqr = wave_sum_d(aul) - beq;
-            if (__builtin_amdgcn_ballot_w64(bad) != 0 || !(fabs(eqr) <= 1e-7 * (1.0 + fabs(beq))))
-                status |= (axis == 0 ? ISMPC_A_ST_X_INFEASIBLE : ISMPC_A_ST_Y_INFEASIBLE) | ISMPC_A_ST_UNVERIFIED;
-        }
-
         if (hist != nullptr) {
             unsigned long long* hq = hist + (size_t)work * 8;
 #pragma unroll
