@@ -1,21 +1,24 @@
 // Formulation A (classic ISMPC with footstep adaptation) on gfx950: kernels + the C ABI of include/ismpc_a.h.
 //
-// One 256-thread workgroup solves ONE per-axis QP of one instance (walking/quad_walk_no_plots.m:153-293):
+// The per-axis QP of one instance (walking/quad_walk_no_plots.m:153-293):
 //
 //   min 1/2 |u|^2 + Qf/2 |f - p|^2      u = ZMP velocities (C), f = footsteps (F)
 //   s.t. a'u = b                          stability (anticipative tail)          (:227-242)
 //        lo_i <= dt cumsum(u)_i - M_i f <= hi_i     ZMP band around the mapped footstep  (:153-181)
 //        -bl_r <= f_r - f_{r-1} <= bu_r             kinematic                           (:187-222)
 //
-// The reference hands the stacked dense matrices to quadprog (MATLAB) / qpOASES / HPIPM.  Here the Hessian
-// is diagonal and every row has a closed form, so a DUAL ACTIVE-SET method in RANGE-SPACE form never builds
-// a matrix over the variables: with N the active normals it keeps S^-1 = (N' H^-1 N)^-1 (size = working
-// set), whose entries come from closed-form inner products (dt^2 min(i,k) + M_i.M_k / Qf, ...).  A step is
-//   d = N' H^-1 n+ (O(1) per active row),  r = S^-1 d (mat-vec),  z = H^-1 (n+ - N r) (impulses + one
-//   suffix scan),  step lengths exactly as Goldfarb-Idnani,  then a rank-1 border (add) or Schur (drop)
-//   update of S^-1 -- all data parallel, no triangular solve, no Givens chain.
-// After convergence two refinement passes on the final working set remove the drift of the explicit
-// inverse and the feasibility of every row is re-checked (the loop resumes if anything moved).
+// The reference hands the stacked dense matrices to quadprog (MATLAB) / qpOASES / HPIPM.  Here the Hessian is
+// diagonal and every row has a closed form, so a DUAL ACTIVE-SET method in RANGE-SPACE form never builds a matrix
+// over the variables.  Two kernels:
+//
+//  * ismpc_a_tick_wave<RL, F, PI> (default): ONE WAVEFRONT per QP, nothing of working-set size is stored.  The Gram
+//    block of the active ZMP rows is dt^2 min(i, k) (a random walk's covariance: tridiagonal inverse, only the gaps
+//    between consecutive active rows matter) plus a border of rank <= 2F+1 with closed-form rows; block warm start
+//    (primal-dual active-set passes, one structured solve per pass) in front of Goldfarb-Idnani; optional
+//    per-instance gait parameters; closed-loop first guess from the previous tick.  DESIGN.md section 2.6.
+//  * ismpc_a_tick_kernel (ISMPC_A_KERNEL=block, A/B reference and F > 6): one 256-thread workgroup per QP with an
+//    explicit S^-1 = (N' H^-1 N)^-1 of working-set size, rank-1 border / Schur updates, two refinement passes.
+//
 // Results are the unique minimiser: validated against the oracle's null-space Goldfarb-Idnani and the
 // reference's qpOASES (tests/).  No CPU fallback.
 #include <hip/hip_runtime.h>
