@@ -35,16 +35,26 @@ def algorithmic_flops_per_tick(N):
 
 
 def measured_traffic(N, B):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_affine_b8192.json:
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_quad_b8192.json:
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads, + WRITE_SIZE), scaled by
     instances per launch; None when no profile of this kernel/horizon is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_affine_b8192.json")
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_quad_b8192.json")
     if not os.path.exists(path) or os.environ.get("ISMPC_PATH") == "dense":
         return None
     j = json.load(open(path))
     if j.get("horizon") != N:
         return None
     return j["derived"]["hbm_bytes_per_launch"] * B / j["batch"]
+
+
+def kernel_name(N):
+    """The dominant kernel of the step, as rocprofv3 names it (csrc/ismpc_hip.hip launch())."""
+    path = os.environ.get("ISMPC_PATH")
+    if path == "dense":
+        return "ismpc_tick_dense<%d, 16>" % ((N + 63) // 64)
+    if path == "wave" or N > 128:
+        return "ismpc_tick_affine<%d>" % ((N + 63) // 64)
+    return "ismpc_tick_quad<%d>" % ((N + 15) // 16)        # four instances per wavefront (flat reference plan)
 
 
 def cpu_baseline(N, tick_in, budget_s=20.0):
@@ -216,11 +226,11 @@ def main():
             "qp_solves_per_s": 3.0 * value,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS, "traffic": measured_traffic(N, B),
-                         "kernel": ("ismpc_tick_dense<%d,16>" if os.environ.get("ISMPC_PATH") == "dense" else "ismpc_tick_affine<%d>") % ((N + 63) // 64), "kernel_ms": kernel_ms, "step_interval_ms": step_interval_ms,
+                         "kernel": kernel_name(N), "kernel_ms": kernel_ms, "step_interval_ms": step_interval_ms,
                          "algorithmic_flops_per_launch": flops,
                          "note": "FP64 compute roofline (vector = matrix peak 78.6 TF); algorithmic flops 6N^2+20N per tick, "
                                  "shared vertical factor; algorithmic HBM bytes 152 B/tick are ~1e-4 of the HBM roofline; "
-                                 "traffic = HBM bytes/launch from rocprofv3 PMC (profiles/r01/pmc_affine_b8192.json), "
+                                 "traffic = HBM bytes/launch from rocprofv3 PMC (profiles/r01/pmc_quad_b8192.json), "
                                  "measured at 8192 instances/launch and scaled linearly to this batch"},
         }
         if small is not None:

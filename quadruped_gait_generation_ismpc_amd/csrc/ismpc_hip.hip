@@ -51,6 +51,10 @@ struct DevConst {
     // inequality fallback (0 <= S u <= 1e4 active)
     const double *HSt, *SHSt;
     int* zflag;                       // id of the last launch that deferred an instance to the fallback kernel
+    // sample-major copies for ismpc_tick_quad: a lane's R samples are one contiguous run (16-byte loads, one base address)
+    const double *vq;                 // (npat+1) x NT x 6 : U0,Ua,Ub,SU0,SUa,SUb per sample
+    const double *tzg;                // NT x 2 : tz, tg per sample
+    const double *midxy;              // nmid x 2 : midx, midy per sample
 };
 
 // ---- wavefront (64 lanes) primitives: DPP, no LDS crossbar (ds_bpermute) on the critical path ----
@@ -1013,6 +1017,308 @@ void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
     tick_affine_body<R, false>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
 }
 
+// =====================================================================================================================
+// FOUR instances per wavefront, one 16-lane DPP row each (horizons N <= 128, flat plans).  A horizon of 100 samples
+// fills only 100 of the 128 sample slots of a wavefront and, worse, every scan, reduction and scalar of the tick is paid
+// once per wavefront: with one instance per row the R = ceil(N/16) samples a lane owns are independent work for the
+// FP64 pipe, the scans / reductions are four DPP steps inside a row (no cross-row fold, no readlane), and what used to be
+// wave-uniform is row-uniform.  Same arithmetic as tick_affine_body; instances whose vertical QP has active inequality
+// rows are deferred to the fallback kernel exactly as there.
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ double dpp64b(double old, double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+// DPP move that writes every lane (rotations; shifts with bound_ctrl): no "old" operand, so no register to pre-load
+template <int CTRL, bool BOUND_ZERO>
+__device__ __forceinline__ double dpp64n(double src)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(src), CTRL, 0xf, 0xf, BOUND_ZERO);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(src), CTRL, 0xf, 0xf, BOUND_ZERO);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of the row, in every lane (row_ror:1,2,4,8)
+__device__ __forceinline__ double row_sum(double v)
+{
+    v += dpp64n<0x121, false>(v);
+    v += dpp64n<0x122, false>(v);
+    v += dpp64n<0x124, false>(v);
+    v += dpp64n<0x128, false>(v);
+    return v;
+}
+__device__ __forceinline__ int row_sum_i(int v)
+{
+    v += __builtin_amdgcn_mov_dpp(v, 0x121, 0xf, 0xf, false);
+    v += __builtin_amdgcn_mov_dpp(v, 0x122, 0xf, 0xf, false);
+    v += __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, false);
+    v += __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false);
+    return v;
+}
+// y <- T y for T = I + Tm taken from lane + CTRL of the row (Tm = 0 past the end of the row)
+template <int CTRL>
+__device__ __forceinline__ void row_scan_step(M2& y)
+{
+    const double ta = dpp64n<CTRL, true>(y.a - 1.0), tb = dpp64n<CTRL, true>(y.b), tc = dpp64n<CTRL, true>(y.c), td = dpp64n<CTRL, true>(y.d - 1.0);
+    M2 r;
+    r.a = fma(ta, y.a, fma(tb, y.c, y.a)); r.b = fma(ta, y.b, fma(tb, y.d, y.b));
+    r.c = fma(tc, y.a, fma(td, y.c, y.c)); r.d = fma(tc, y.b, fma(td, y.d, y.d));
+    y = r;
+}
+// lane 0 of the row, in every lane: quad_perm [0,0,0,0], then row_shr:4 into bank 1, row_shr:8 into banks 2,3
+__device__ __forceinline__ double row_bcast0(double v)
+{
+    v = dpp64b<0x000, 0xf>(v, v);
+    v = dpp64b<0x114, 0x2>(v, v);
+    v = dpp64b<0x118, 0xc>(v, v);
+    return v;
+}
+
+template <int R>
+__device__ __forceinline__ void tick_quad_body(const DevConst& c, const int gi_raw, const int batch, const int lane,
+                                               const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
+                                               ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
+                                               int rollout_frame, unsigned char* zmark, int launch_id)
+{
+    constexpr int NT = ismpc::Tables::NT;
+    const int N = c.N;
+    const int li = lane & 15;                         // lane inside the row = inside the instance
+    const bool valid = gi_raw < batch;
+    const int gi = valid ? gi_raw : batch - 1;        // tail rows recompute the last instance and store nothing
+    const double dt = c.dt;
+    const ismpc_tick_in* rec = ((rollout_frame >= 0) ? state_rw : in_ro) + gi;
+    const Walk w = load_walk(c, rec, rollout_frame);
+    const double x0 = rec->com_pos[0], y0 = rec->com_pos[1], z0 = rec->com_pos[2];
+    const double xd0 = rec->com_vel[0], yd0 = rec->com_vel[1], zd0 = rec->com_vel[2];
+    int idx;
+    const int gate_status = gate_tick(c, w, idx);     // row-uniform; a gated row runs the arithmetic on idx = 0 and drops it
+    int status = gate_status;
+    const bool run = gate_status == 0;
+    if (!run) idx = 0;
+    const int n0 = li * R;                            // this lane owns samples n0 .. n0+R-1 (tables are zero past N)
+
+    // ---- vertical stage from the affine tables (MPCSolver.cpp:223-243, is_running :262-263)
+    const int pat = (run && w.fc > 1 && w.mpc < c.npat) ? w.mpc : c.npat;
+    const double2* T = reinterpret_cast<const double2*>(c.vq + ((size_t)pat * NT + n0) * 6);     // 3 x 16 bytes per sample
+    double u[R], su[R];
+    double smin = INFINITY, smax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double2 t01 = T[3 * r], t23 = T[3 * r + 1], t45 = T[3 * r + 2];
+        u[r] = fma(zd0, t23.x, fma(z0, t01.y, t01.x));
+        su[r] = fma(zd0, t45.y, fma(z0, t45.x, t23.y));
+        if (n0 + r < N) { smin = fmin(smin, su[r]); smax = fmax(smax, su[r]); }
+    }
+    const double zlo_t = c.z_lo - 1e-11 * fmax(1.0, fabs(c.z_lo)), zhi_t = c.z_hi + 1e-11 * fmax(1.0, fabs(c.z_hi));
+    const bool viol = smin < zlo_t || smax > zhi_t;                                                // MPCSolver.cpp:158-160, beyond rounding
+    const unsigned long long vmask = __builtin_amdgcn_ballot_w64(viol);
+    const bool deferred = run && (((vmask >> (lane & 48)) & 0xffffull) != 0ull);
+    if (deferred) status |= ISMPC_ST_Z_INEQ_ACTIVE;
+
+    // ---- lambda_j (MPCSolver.cpp:306) and A_j, B_j (:353-361): A = [1+wQ, dt P; lam dt P, 1+wQ], B = [-wQ, -lam dt P]
+    double ch1[R], s1[R], s2[R], lam0_l = 0.0;
+    bool big = false, mid = false;
+    {
+        double wv_[R], le_[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double2 tq = reinterpret_cast<const double2*>(c.tzg)[n0 + r];
+            const double zpos = su[r] + fma(tq.x, zd0, z0) + tq.y;                  // S u + T_bar_z s + T_bar_g_z
+            const double zacc = c.inv_mass * u[r] - c.g;
+            const double lam = (c.g + zacc) * frcp(zpos);
+            if (r == 0) lam0_l = lam;
+            le_[r] = (lam < c.gate) ? 0.0 : lam;
+            const double dtn = (n0 + r < N) ? dt : 0.0;
+            wv_[r] = le_[r] * dtn * dtn;
+            s1[r] = dtn;                                  // dt_n for now
+            big = big || (wv_[r] > 0.25);
+            mid = mid || (wv_[r] > 0.004);
+        }
+        if (__builtin_amdgcn_ballot_w64(mid) == 0) {      // degree 3 is exact to < 1 ulp for w <= 0.004 (see tick_affine_body)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double wv = wv_[r];
+                double P = 1.0 / 5040.0, Q = 1.0 / 40320.0;
+                P = fma(P, wv, 1.0 / 120.0);         Q = fma(Q, wv, 1.0 / 720.0);
+                P = fma(P, wv, 1.0 / 6.0);           Q = fma(Q, wv, 1.0 / 24.0);
+                P = fma(P, wv, 1.0);                 Q = fma(Q, wv, 0.5);
+                ch1[r] = wv * Q; s1[r] = s1[r] * P; s2[r] = le_[r] * s1[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double wv = wv_[r], dtn = s1[r];
+                double P = 1.0 / 1307674368000.0, Q = 1.0 / 20922789888000.0;
+                P = fma(P, wv, 1.0 / 6227020800.0);  Q = fma(Q, wv, 1.0 / 87178291200.0);
+                P = fma(P, wv, 1.0 / 39916800.0);    Q = fma(Q, wv, 1.0 / 479001600.0);
+                P = fma(P, wv, 1.0 / 362880.0);      Q = fma(Q, wv, 1.0 / 3628800.0);
+                P = fma(P, wv, 1.0 / 5040.0);        Q = fma(Q, wv, 1.0 / 40320.0);
+                P = fma(P, wv, 1.0 / 120.0);         Q = fma(Q, wv, 1.0 / 720.0);
+                P = fma(P, wv, 1.0 / 6.0);           Q = fma(Q, wv, 1.0 / 24.0);
+                P = fma(P, wv, 1.0);                 Q = fma(Q, wv, 0.5);
+                ch1[r] = wv * Q; s1[r] = dtn * P; s2[r] = le_[r] * s1[r];
+                if (__builtin_amdgcn_ballot_w64(big) != 0 && wv > 0.25) {     // lambda dt^2 > 1/4: off any physical gait; libm
+                    const double x = sqrt(wv);
+                    ch1[r] = cosh(x) - 1.0; s1[r] = dtn * (sinh(x) / x); s2[r] = le_[r] * s1[r];
+                }
+            }
+        }
+    }
+    // ---- inclusive suffix product over the row: Y_l = A(block 15) ... A(block l); C_sc = [1, 1/eta]
+    M2 Y = (M2){1.0 + ch1[0], s1[0], s2[0], 1.0 + ch1[0]};
+#pragma unroll
+    for (int r = 1; r < R; ++r) Y = mul((M2){1.0 + ch1[r], s1[r], s2[r], 1.0 + ch1[r]}, Y);
+    row_scan_step<0x101>(Y); row_scan_step<0x102>(Y); row_scan_step<0x104>(Y); row_scan_step<0x108>(Y);   // row_shl 1,2,4,8
+    const double ie = c.inv_eta;
+    const double cva = fma(ie, Y.c, Y.a), cvb = fma(ie, Y.d, Y.b);       // C_sc (suffix product from this lane's first sample)
+    double c0 = dpp64<0x101, 0xf, false>(1.0, cva), c1 = dpp64<0x101, 0xf, false>(ie, cvb);          // the lane needs it one lane up
+    // ---- Aeq(n) = C_sc phi_input(:,n) = c_n B_n, walking the lane's samples backwards
+    double a[R];
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) {
+        a[r] = -(c0 * ch1[r] + c1 * s2[r]);
+        const double k0 = fma(c0, ch1[r], fma(c1, s2[r], c0)), k1 = fma(c1, ch1[r], fma(c0, s1[r], c1));
+        c0 = k0; c1 = k1;
+    }
+    const double h = (w.fc > 1) ? c.half_run : c.half_first;                                          // MPCSolver.cpp:328-338
+    double q0 = 0.0, s_ax = 0.0, s_ay = 0.0, mx0 = 0.0, my0 = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int n = n0 + r;
+        const double2 mq = reinterpret_cast<const double2*>(c.midxy)[min(idx + n, c.nmid - 1)];
+        const double mx = (n < N) ? mq.x : 0.0, my = (n < N) ? mq.y : 0.0;
+        if (r == 0) { mx0 = mx; my0 = my; }
+        q0 = fma(a[r], a[r], q0); s_ax = fma(a[r], mx, s_ax); s_ay = fma(a[r], my, s_ay);
+    }
+    q0 = row_sum(q0); s_ax = row_sum(s_ax); s_ay = row_sum(s_ay);
+    // C_sc phi_state sits in lane 0 of the row (cva, cvb there); beq - a'mid (MPCSolver.cpp:381-384), row-uniform
+    const double bpx = row_bcast0((c.tailx[idx] - fma(cva, x0, cvb * xd0)) - s_ax);
+    const double bpy = row_bcast0((c.taily[idx] - fma(cva, y0, cvb * yd0)) - s_ay);
+    const double sgx = (bpx < 0.0) ? -1.0 : 1.0, sgy = (bpy < 0.0) ? -1.0 : 1.0;
+    // min 1/2|v|^2, a'v = bp, |v| <= h  ->  v_n = sg sign(a_n) min(tau |a_n|, h): Newton on the concave piecewise-linear
+    // G(tau) = sum |a_n| min(tau |a_n|, h) from tau = 0; the four rows iterate in lockstep, each with its own state
+    const double Tq[2] = { fabs(bpx), fabs(bpy) };
+    const double iq0 = frcp(q0);
+    double tau[2] = { Tq[0] * iq0, Tq[1] * iq0 };
+    int its[2] = {1, 1}, prev[2] = {0, 0};
+    bool live[2] = {true, true};
+    int st3 = 0;
+    double aa[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) aa[r] = fabs(a[r]);
+    if (!(q0 > 0.0)) {                                                       // no sample can move the ZMP
+#pragma unroll
+        for (int ax = 0; ax < 2; ++ax) {
+            tau[ax] = (Tq[ax] > 0.0) ? INFINITY : 0.0;
+            if (Tq[ax] > 1e-300) st3 |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
+        }
+    }
+    for (int it = 0; it < N + 2; ++it) {
+        if (__builtin_amdgcn_ballot_w64(live[0] || live[1]) == 0ull) break;
+#pragma unroll
+        for (int ax = 0; ax < 2; ++ax) {
+            int cl = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) cl += (tau[ax] * aa[r] >= h) ? 1 : 0;
+            const int cnt = row_sum_i(cl);
+            if (live[ax] && cnt == prev[ax]) live[ax] = false;                // active set unchanged: exact
+            if (__builtin_amdgcn_ballot_w64(live[ax]) == 0ull) continue;
+            double ssat = 0.0, qfree = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const bool sat = tau[ax] * aa[r] >= h; ssat += sat ? aa[r] : 0.0; qfree += sat ? 0.0 : a[r] * a[r]; }
+            ssat = row_sum(ssat); qfree = row_sum(qfree);
+            if (live[ax]) {
+                ++its[ax];
+                const double rem = Tq[ax] - h * ssat;
+                if (!(qfree > 0.0)) {                                         // everything saturated
+                    if (rem > h * ssat * 1e-12 + 1e-300) st3 |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
+                    tau[ax] = INFINITY; live[ax] = false;
+                } else {
+                    const double tn = rem * frcp(qfree);
+                    if (!(tn > tau[ax])) live[ax] = false;
+                    else { tau[ax] = tn; prev[ax] = cnt; }
+                }
+            }
+        }
+    }
+
+    // ---- lane 0 of the row finishes the instance: integration (MPCSolver.cpp:274-278, 406-422), record, feedback
+    if (li == 0 && valid) {
+        double o_x = x0, o_y = y0, o_z = z0, o_xd = xd0, o_yd = yd0, o_zd = zd0;
+        double uz0 = 0.0, ux0 = 0.0, uy0 = 0.0;
+        int itx = 0, ity = 0;
+        if (run) {
+            uz0 = u[0];
+            o_z = z0 + dt * zd0;
+            o_zd = zd0 + c.dt_over_mass * uz0 - dt * c.g;
+            if (isnan(o_z)) { o_z = c.h_des; status |= ISMPC_ST_Z_NAN; }
+            if (isnan(o_zd)) { o_zd = 0.0; status |= ISMPC_ST_Z_NAN; }
+            const double A0a = 1.0 + ch1[0], A0b = s1[0], A0c = s2[0];
+            if (lam0_l > c.gate) {                                            // MPCSolver.cpp:322
+                status |= st3; itx = its[0]; ity = its[1];
+                const double sa0 = (a[0] < 0.0) ? -1.0 : 1.0;
+                ux0 = mx0 + sgx * sa0 * ((aa[0] > 0.0) ? fmin(tau[0] * aa[0], h) : 0.0);
+                uy0 = my0 + sgy * sa0 * ((aa[0] > 0.0) ? fmin(tau[1] * aa[0], h) : 0.0);
+            } else status |= ISMPC_ST_FLIGHT;
+            o_x  = (A0a * x0 + A0b * xd0) + (1.0 - A0a) * ux0;
+            o_xd = (A0c * x0 + A0a * xd0) - A0c * ux0;
+            o_y  = (A0a * y0 + A0b * yd0) + (1.0 - A0a) * uy0;
+            o_yd = (A0c * y0 + A0a * yd0) - A0c * uy0;
+        }
+        if (out) {
+            double2* o2 = reinterpret_cast<double2*>(out + gi);
+            const long long packed = (long long)(unsigned)status | ((long long)(unsigned)((itx & 255) | ((ity & 255) << 8)) << 32);
+            o2[0] = make_double2(o_x, o_y); o2[1] = make_double2(o_z, o_xd); o2[2] = make_double2(o_yd, o_zd);
+            o2[3] = make_double2(uz0, ux0); o2[4] = make_double2(uy0, __longlong_as_double(packed));
+        }
+        if (zmark) zmark[gi] = deferred ? 1 : 0;
+        if (deferred) atomicMax(c.zflag, launch_id);
+        if (rollout_frame >= 0 && !deferred) {                               // Controller.cpp:346-348, :503-504
+            ismpc_tick_in* st = state_rw + gi;
+            st->com_pos[0] = o_x; st->com_pos[1] = o_y; st->com_pos[2] = o_z;
+            st->com_vel[0] = o_xd; st->com_vel[1] = o_yd; st->com_vel[2] = o_zd;
+            st->simulation_time = w.sim;
+            const int ctl = w.ctl + 1;
+            st->control_iter = ctl;
+            st->mpc_iter = (int)floor(ctl * c.cdt / c.dt);     // as written at Controller.cpp:504 (see tick_affine_body)
+            st->footstep_counter = w.fc;
+        }
+    }
+    if (u_traj && valid) {
+        const bool stage3 = run && row_bcast0(lam0_l) > c.gate;
+        double* dst = u_traj + (size_t)gi * 3 * N;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = n0 + r;
+            if (n < N) {
+                double vx = 0.0, vy = 0.0;
+                if (stage3) {
+                    const double sa = (a[r] < 0.0) ? -1.0 : 1.0;
+                    vx = c.midx[idx + n] + sgx * sa * ((aa[r] > 0.0) ? fmin(tau[0] * aa[r], h) : 0.0);
+                    vy = c.midy[idx + n] + sgy * sa * ((aa[r] > 0.0) ? fmin(tau[1] * aa[r], h) : 0.0);
+                }
+                dst[n] = run ? u[r] : 0.0; dst[N + n] = vx; dst[2 * N + n] = vy;
+            }
+        }
+    }
+}
+
+#ifndef ISMPC_QUAD_WAVES
+#define ISMPC_QUAD_WAVES 4
+#endif
+template <int R>
+__global__ __launch_bounds__(64 * ISMPC_QUAD_WAVES)
+void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
+                     ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
+                     unsigned char* zmark, int launch_id)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave * 4 >= batch) return;
+    tick_quad_body<R>(c, wave * 4 + (lane >> 4), batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+}
+
 // Second launch of every tick: exits at once unless the first one deferred instances (active inequality rows).
 template <int R>
 __global__ __launch_bounds__(256)
@@ -1048,6 +1354,7 @@ struct ismpc_handle {
     int force_waves = 0;      // dense path: 4, 8 or 16 wavefronts per workgroup (0 = 16)
     unsigned char* zmark = nullptr; int zmark_cap = 0; int launch_id = 0; bool z_fallback = true;
     bool dense_path = false;  // true: per-tick MFMA solve (ismpc_tick_dense); false: affine tables (ismpc_tick_affine)
+    bool quad_path = true;    // affine tables, four instances per wavefront (ismpc_tick_quad) where it applies; ISMPC_PATH=wave: one per wavefront
 };
 
 namespace {
@@ -1081,6 +1388,27 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
         unsigned char* zm = h->z_fallback ? h->zmark : nullptr;
         const int lid = ++h->launch_id;
         const dim3 fgrid(std::min((batch + 3) / 4, 64));
+        // default for flat plans and N <= 128: four instances per wavefront (ismpc_tick_quad); ISMPC_PATH=wave keeps one per wavefront
+        if (h->quad_path && h->c.flat && h->c.N <= 128) {
+            const int RQ = (h->c.N + 15) / 16;
+            const int waves = (batch + 3) / 4;
+            const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
+#define ISMPC_QUAD(RR) hipLaunchKernelGGL(ismpc_tick_quad<RR>, qgrid, qblock, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid)
+            switch (RQ) {
+                case 1: ISMPC_QUAD(1); break; case 2: ISMPC_QUAD(2); break; case 3: ISMPC_QUAD(3); break; case 4: ISMPC_QUAD(4); break;
+                case 5: ISMPC_QUAD(5); break; case 6: ISMPC_QUAD(6); break; case 7: ISMPC_QUAD(7); break; default: ISMPC_QUAD(8); break;
+            }
+#undef ISMPC_QUAD
+            if (zm) {
+                switch (R) {
+                    case 1: hipLaunchKernelGGL(ismpc_tick_affine_fallback<1>, fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); break;
+                    case 2: hipLaunchKernelGGL(ismpc_tick_affine_fallback<2>, fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); break;
+                    default: return fail(ISMPC_E_UNSUPPORTED, "horizon N > 128 on the quad path");
+                }
+            }
+            HIP_TRY(hipGetLastError());
+            return ISMPC_OK;
+        }
 #define ISMPC_AFF(RR) do { \
         hipLaunchKernelGGL(ismpc_tick_affine<RR>, dim3((batch + ISMPC_AFF_WAVES - 1) / ISMPC_AFF_WAVES), dim3(64 * ISMPC_AFF_WAVES), 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); \
         if (zm) hipLaunchKernelGGL(ismpc_tick_affine_fallback<RR>, fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); \
@@ -1157,7 +1485,7 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
         const int v = std::atoi(fw);
         if (v == 4 || v == 8 || v == 16) h->force_waves = v;
     }
-    if (const char* pth = std::getenv("ISMPC_PATH")) h->dense_path = std::strcmp(pth, "dense") == 0;
+    if (const char* pth = std::getenv("ISMPC_PATH")) { h->dense_path = std::strcmp(pth, "dense") == 0; h->quad_path = std::strcmp(pth, "wave") != 0 && !h->dense_path; }
     if (const char* zf = std::getenv("ISMPC_Z_FALLBACK")) h->z_fallback = std::atoi(zf) != 0;   // 0: flag only, no second launch
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete h; return fail(ISMPC_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
@@ -1191,6 +1519,19 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     if (rc == ISMPC_OK) rc = upload(h, t.HSt, &c.HSt);
     if (rc == ISMPC_OK) rc = upload(h, t.SHSt, &c.SHSt);
     if (rc == ISMPC_OK) { std::vector<int> zf(1, 0); const int* zp = nullptr; rc = upload(h, zf, &zp); c.zflag = const_cast<int*>(zp); }
+    if (rc == ISMPC_OK) {
+        constexpr int NTq = ismpc::Tables::NT;
+        const size_t npp = t.vtab.size() / (6 * (size_t)NTq);
+        std::vector<double> vq(t.vtab.size()), tzg(2 * (size_t)NTq), mxy(2 * t.midx.size());
+        for (size_t pp = 0; pp < npp; ++pp)
+            for (int k = 0; k < 6; ++k)
+                for (int n = 0; n < NTq; ++n) vq[(pp * NTq + n) * 6 + k] = t.vtab[(pp * 6 + k) * NTq + n];
+        for (int n = 0; n < NTq; ++n) { tzg[2 * n] = t.tz[n]; tzg[2 * n + 1] = t.tg[n]; }
+        for (size_t n = 0; n < t.midx.size(); ++n) { mxy[2 * n] = t.midx[n]; mxy[2 * n + 1] = t.midy[n]; }
+        rc = upload(h, vq, &c.vq);
+        if (rc == ISMPC_OK) rc = upload(h, tzg, &c.tzg);
+        if (rc == ISMPC_OK) rc = upload(h, mxy, &c.midxy);
+    }
     c.flat = t.flat ? 1 : 0;
     if (rc != ISMPC_OK) { ismpc_destroy(h); return rc; }
     if (hipStreamCreate(&h->own_stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||

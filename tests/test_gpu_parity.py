@@ -32,7 +32,7 @@ def O():
 
 
 _solvers = {}
-PATHS = ("affine", "dense")     # fast path (affine tables) and the per-tick MFMA formulation
+PATHS = ("affine", "wave", "dense")     # affine tables: four instances per wavefront where it applies (default) / one per wavefront; per-tick MFMA formulation
 
 
 def solver_for(q, N, path="affine", plan=None, **over):
