@@ -189,7 +189,7 @@ def runs_of(W, C):
     return out
 
 
-def hybrid2(H, g, E, b, N, lo, hi, C, max_add, max_drop, grow=2, cap=64, strict_ends=False):
+def hybrid2(H, g, E, b, N, lo, hi, C, max_add, max_drop, grow=2, cap=64, strict_ends=False, first='all'):
     """PDAS passes with geometric peeling at run ends; drop-only passes at the end; then GI.  (passes, cold, GI steps, x)"""
     W = {}; x, mu = solve_on(H, g, E, b, N, lo, hi, W)
     D = 1; npass = 0; cold = 0
@@ -212,8 +212,14 @@ def hybrid2(H, g, E, b, N, lo, hi, C, max_add, max_drop, grow=2, cap=64, strict_
         if adding:
             cv = N @ x
             tol = 1e-11 * (np.abs(cv) + np.maximum(np.abs(lo), np.abs(hi))) + 1e-13
-            for r in np.nonzero(cv[:C] < (lo - tol)[:C])[0]: new.setdefault(int(r), +1)
-            for r in np.nonzero(cv[:C] > (hi + tol)[:C])[0]: new.setdefault(int(r), -1)
+            vl = np.maximum(lo - cv, 0.0)[:C]; vh = np.maximum(cv - hi, 0.0)[:C]
+            viol = np.maximum(vl, vh)
+            thr = 0.0
+            if first == 'half' and p == 0: thr = 0.5 * viol.max()
+            if first == 'q' and p == 0: thr = 0.25 * viol.max()
+            if first == 'half2' and p <= 1: thr = 0.5 * viol.max()
+            for r in np.nonzero((cv[:C] < (lo - tol)[:C]) & (viol >= thr))[0]: new.setdefault(int(r), +1)
+            for r in np.nonzero((cv[:C] > (hi + tol)[:C]) & (viol >= thr))[0]: new.setdefault(int(r), -1)
         if new == W: break
         if p >= max_add + max_drop:
             W = {}; x, mu = solve_on(H, g, E, b, N, lo, hi, W); cold = 1; break
@@ -223,7 +229,7 @@ def hybrid2(H, g, E, b, N, lo, hi, C, max_add, max_drop, grow=2, cap=64, strict_
     return npass, cold, steps, x
 
 
-def study2(name, ntest, cfgs=((12, 8, 1), (12, 8, 2), (6, 6, 2), (4, 6, 2), (8, 8, 2))):
+def study2(name, ntest, cfgs=((4, 6, 2, 'all'), (4, 6, 2, 'half'), (4, 6, 2, 'q'), (4, 6, 2, 'half2'), (6, 6, 2, 'half2'))):
     z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"prerollA_{name}.npz"))
     kind = int(z["gait"]); p = A.params(kind, C_=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
     sim = A.SimA(A.gait(kind, float(z["phi"]), float(z["disp_A"])), p, backend="gi")
@@ -240,14 +246,14 @@ def study2(name, ntest, cfgs=((12, 8, 1), (12, 8, 2), (6, 6, 2), (4, 6, 2), (8, 
             Q = build(D, p.dt, p.Qf)
             xs = None
             for c in cfgs:
-                npass, cold, steps, x = hybrid2(*Q, p.C, c[0], c[1], grow=c[2])
+                npass, cold, steps, x = hybrid2(*Q, p.C, c[0], c[1], grow=c[2], first=(c[3] if len(c) > 3 else 'all'))
                 if xs is None: xs = x
                 assert np.abs(x - xs).max() < 1e-7 * max(1, np.abs(xs).max()), (c, np.abs(x - xs).max())
                 res[c].append((npass, cold, steps))
         sim.state = st
     for c in cfgs:
         r = np.array(res[c])
-        print(f"{name} add<={c[0]} drop<={c[1]} grow={c[2]}: passes {r[:,0].mean():.2f} cold {r[:,1].mean():.2f} GI steps {r[:,2].mean():.1f}  "
+        print(f"{name} add<={c[0]} drop<={c[1]} grow={c[2]} first={c[3] if len(c) > 3 else 'all'}: passes {r[:,0].mean():.2f} cold {r[:,1].mean():.2f} GI steps {r[:,2].mean():.1f}  "
               f"work(1.2/pass) {(1.2 * r[:,0] + r[:,2]).mean():.1f}   max GI {r[:,2].max()}")
 
 if __name__ == "__main__" and os.environ.get("STUDY2"):
