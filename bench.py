@@ -54,7 +54,7 @@ def kernel_name(N):
         return "ismpc_tick_dense<%d, 16>" % ((N + 63) // 64)
     if path == "wave" or N > 128:
         return "ismpc_tick_affine<%d>" % ((N + 63) // 64)
-    return "ismpc_tick_quad<%d>" % ((N + 15) // 16)        # four instances per wavefront (flat reference plan)
+    return "ismpc_tick_quad<%d>" % ((N + 15) // 16)        # four instances per wavefront
 
 
 def cpu_baseline(N, tick_in, budget_s=20.0):

@@ -1018,7 +1018,7 @@ void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
 }
 
 // =====================================================================================================================
-// FOUR instances per wavefront, one 16-lane DPP row each (horizons N <= 128, flat plans).  A horizon of 100 samples
+// FOUR instances per wavefront, one 16-lane DPP row each (horizons N <= 128).  A horizon of 100 samples
 // fills only 100 of the 128 sample slots of a wavefront and, worse, every scan, reduction and scalar of the tick is paid
 // once per wavefront: with one instance per row the R = ceil(N/16) samples a lane owns are independent work for the
 // FP64 pipe, the scans / reductions are four DPP steps inside a row (no cross-row fold, no readlane), and what used to be
@@ -1109,6 +1109,34 @@ __device__ __forceinline__ void tick_quad_body(const DevConst& c, const int gi_r
         u[r] = fma(zd0, t23.x, fma(z0, t01.y, t01.x));
         su[r] = fma(zd0, t45.y, fma(z0, t45.x, t23.y));
         if (n0 + r < N) { smin = fmin(smin, su[r]); smax = fmax(smax, su[r]); }
+    }
+    if (!c.flat) {                                      // plans with mid_z != 0 (MPCSolver.cpp:259): per-frame offsets, pattern corrections
+        int elo = 0, ne = 0;
+        if (pat < c.npat) { elo = c.e_lo[pat]; ne = c.ne[pat]; }
+        const int pp = pat < c.npat ? pat : 0;
+        const int nemax = max(max(__builtin_amdgcn_readlane(ne, 0), __builtin_amdgcn_readlane(ne, 16)),
+                              max(__builtin_amdgcn_readlane(ne, 32), __builtin_amdgcn_readlane(ne, 48)));
+        const double* dUr = c.dU + (size_t)idx * NT;
+        const double* sUr = c.SdU + (size_t)idx * NT;
+        double du[R], ds[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { du[r] = dUr[n0 + r]; ds[r] = sUr[n0 + r]; }
+        for (int e = 0; e < nemax; ++e) {
+            const bool on = e < ne;
+            const double ue = on ? dUr[elo + e] : 0.0;
+            const double* wr = c.Wt + ((size_t)pp * c.Fmax + (on ? e : 0)) * NT + n0;
+            const double* sr = c.SW + ((size_t)pp * c.Fmax + (on ? e : 0)) * NT + n0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { du[r] -= wr[r] * ue; ds[r] -= sr[r] * ue; }
+        }
+        smin = INFINITY; smax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = n0 + r;
+            u[r] += du[r]; su[r] += ds[r];
+            if (n >= elo && n < elo + ne) u[r] = 0.0;
+            if (n < N) { smin = fmin(smin, su[r]); smax = fmax(smax, su[r]); }
+        }
     }
     const double zlo_t = c.z_lo - 1e-11 * fmax(1.0, fabs(c.z_lo)), zhi_t = c.z_hi + 1e-11 * fmax(1.0, fabs(c.z_hi));
     const bool viol = smin < zlo_t || smax > zhi_t;                                                // MPCSolver.cpp:158-160, beyond rounding
@@ -1388,8 +1416,8 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
         unsigned char* zm = h->z_fallback ? h->zmark : nullptr;
         const int lid = ++h->launch_id;
         const dim3 fgrid(std::min((batch + 3) / 4, 64));
-        // default for flat plans and N <= 128: four instances per wavefront (ismpc_tick_quad); ISMPC_PATH=wave keeps one per wavefront
-        if (h->quad_path && h->c.flat && h->c.N <= 128) {
+        // default for N <= 128: four instances per wavefront (ismpc_tick_quad); ISMPC_PATH=wave keeps one per wavefront
+        if (h->quad_path && h->c.N <= 128) {
             const int RQ = (h->c.N + 15) / 16;
             const int waves = (batch + 3) / 4;
             const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
