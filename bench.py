@@ -102,12 +102,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X: the hot path has no CPU fallback"
+    # ISMPC_BENCH_REHEARSE=1: rehearsal of the multi-rank control flow on a ONE-GPU box -- every rank uses cuda:0 and the
+    # all-gather runs over gloo on host copies.  Not a measurement (the JSON line says so); the driver never sets it.
+    rehearse = world > 1 and os.environ.get("ISMPC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     from quadruped_gait_generation_ismpc_amd.distributed import shard_range, gather_records
     N, B = args.horizon, args.batch_per_gpu
@@ -119,7 +127,11 @@ def main():
     tick_in = workload.make_batch(N, B, first_instance=rank * B)         # this rank's shard, no communication
     d_in = q.to_device(tick_in, dev)
     d_out = torch.empty((B, 80), dtype=torch.uint8, device=dev)
-    d_all = torch.empty((world * B, 80), dtype=torch.uint8, device=dev) if world > 1 else None
+    d_all = torch.empty((world * B, 80), dtype=torch.uint8, device=("cpu" if rehearse else dev)) if world > 1 else None
+    _gather = gather_records
+    if rehearse:
+        def gather_records(local, world_, out=None, counts=None):          # host copies over gloo
+            return _gather(local.cpu(), world_, out=out, counts=counts)
 
     def step():
         solver.solve_batch_torch(d_in, d_out)
@@ -154,7 +166,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=("cpu" if rehearse else dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     step_interval_ms = None
@@ -201,7 +213,7 @@ def main():
 
     out = q.from_device(d_out, q.TICK_OUT)
     if world > 1:
-        allout = q.from_device(d_all, q.TICK_OUT)
+        allout = q.from_device(d_all, q.TICK_OUT) if not rehearse else np.frombuffer(d_all.numpy().tobytes(), dtype=q.TICK_OUT)
         assert allout[rank * B:(rank + 1) * B].tobytes() == out.tobytes(), "all-gather misplaced this rank's shard"
     st = out["status"]
     frac_flight = float(((st & q.ST_FLIGHT) != 0).mean())
@@ -217,7 +229,7 @@ def main():
             "unit": "ticks/s (1 tick = one MPCSolver::solve = 3 QPs: vertical + x + y)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
             "config": {"workload": f"Formulation B (MPCSolver::solve), trot plan Controller.cpp:89-97, N={N}, S=35, F=10, "
                                    f"{B} instances/GPU (shard of BASELINE config 3: 65 536 over 8 GPUs), nominal pre-roll + perturbation (SURVEY 8d)",
                        "horizon": N, "batch_per_gpu": B, "global_batch": world * B,
