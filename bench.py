@@ -47,13 +47,23 @@ def measured_traffic(N, B):
     return j["derived"]["hbm_bytes_per_launch"] * B / j["batch"]
 
 
-def kernel_name(N):
+def one_launch(N, B, cus):
+    """csrc/ismpc_hip.hip launch(): batches whose wavefronts are all resident at once (<= 2 per SIMD) take the variant that
+    runs the inequality fallback inside the same launch."""
+    path = os.environ.get("ISMPC_PATH")
+    return (path not in ("dense", "wave") and N <= 128 and os.environ.get("ISMPC_ONE_LAUNCH") != "0"
+            and os.environ.get("ISMPC_Z_FALLBACK") != "0" and (B + 3) // 4 <= 8 * cus)
+
+
+def kernel_name(N, B, cus):
     """The dominant kernel of the step, as rocprofv3 names it (csrc/ismpc_hip.hip launch())."""
     path = os.environ.get("ISMPC_PATH")
     if path == "dense":
         return "ismpc_tick_dense<%d, 16>" % ((N + 63) // 64)
     if path == "wave" or N > 128:
         return "ismpc_tick_affine<%d>" % ((N + 63) // 64)
+    if one_launch(N, B, cus):
+        return "ismpc_tick_quad_inline<%d, %d>" % ((N + 15) // 16, (N + 63) // 64)
     return "ismpc_tick_quad<%d>" % ((N + 15) // 16)        # four instances per wavefront
 
 
@@ -171,12 +181,16 @@ def main():
         elapsed = float(t.item())
     step_interval_ms = None
     if world == 1:
-        # The product step is two launches (ismpc_tick_affine, then the normally idle inequality fallback).  The roofline
-        # prices the dominant kernel alone: same inputs, same kernel, a handle created with the fallback launch switched
-        # off (ISMPC_Z_FALLBACK=0), K back-to-back launches bracketed by one event pair on the launch stream.
+        # Small batches: the step is ONE launch (ismpc_tick_quad_inline) and the region above already times it.  Large
+        # batches: two launches (ismpc_tick_quad, then the normally idle inequality fallback); the roofline then prices the
+        # dominant kernel alone: same inputs, same kernel, a handle created with the fallback launch switched off
+        # (ISMPC_Z_FALLBACK=0), K back-to-back launches bracketed by one event pair on the launch stream.
         step_interval_ms = ev_region[0].elapsed_time(ev_region[1]) / args.steps
         kernel_ms = step_interval_ms
-        if os.environ.get("ISMPC_PATH") != "dense" and os.environ.get("ISMPC_Z_FALLBACK") != "0":
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        if one_launch(N, B, cus):
+            pass                                          # the step IS one launch of the dominant kernel
+        elif os.environ.get("ISMPC_PATH") != "dense" and os.environ.get("ISMPC_Z_FALLBACK") != "0":
             os.environ["ISMPC_Z_FALLBACK"] = "0"
             try:
                 solo = q.MPCSolver(q.reference_plan(params=p), params=p, device=local_rank)
@@ -238,7 +252,7 @@ def main():
             "qp_solves_per_s": 3.0 * value,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS, "traffic": measured_traffic(N, B),
-                         "kernel": kernel_name(N), "kernel_ms": kernel_ms, "step_interval_ms": step_interval_ms,
+                         "kernel": kernel_name(N, B, torch.cuda.get_device_properties(dev).multi_processor_count), "kernel_ms": kernel_ms, "step_interval_ms": step_interval_ms,
                          "algorithmic_flops_per_launch": flops,
                          "note": "FP64 compute roofline (vector = matrix peak 78.6 TF); algorithmic flops 6N^2+20N per tick, "
                                  "shared vertical factor; algorithmic HBM bytes 152 B/tick are ~1e-4 of the HBM roofline; "

@@ -1076,7 +1076,7 @@ __device__ __forceinline__ double row_bcast0(double v)
 }
 
 template <int R>
-__device__ __forceinline__ void tick_quad_body(const DevConst& c, const int gi_raw, const int batch, const int lane,
+__device__ __forceinline__ bool tick_quad_body(const DevConst& c, const int gi_raw, const int batch, const int lane,
                                                const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                                                ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
                                                int rollout_frame, unsigned char* zmark, int launch_id)
@@ -1330,6 +1330,7 @@ __device__ __forceinline__ void tick_quad_body(const DevConst& c, const int gi_r
             }
         }
     }
+    return deferred && valid;
 }
 
 #ifndef ISMPC_QUAD_WAVES
@@ -1345,6 +1346,27 @@ void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, 
     const int wave = blockIdx.x * ISMPC_QUAD_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave * 4 >= batch) return;
     tick_quad_body<R>(c, wave * 4 + (lane >> 4), batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+}
+
+// Latency variant for small batches (every wavefront resident at once): a wavefront that deferred one of its four
+// instances runs the inequality fallback for it right away, with all 64 lanes, so a step is ONE launch.  The price is
+// the fallback's register budget (2 waves per SIMD), which is why large batches keep the two-launch form.
+template <int R, int RW>
+__global__ __launch_bounds__(64 * ISMPC_QUAD_WAVES)
+void ismpc_tick_quad_inline(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
+                            ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
+                            unsigned char* zmark, int launch_id)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave * 4 >= batch) return;
+    const bool def = tick_quad_body<R>(c, wave * 4 + (lane >> 4), batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+    unsigned long long m = __builtin_amdgcn_ballot_w64(def);
+    if (m == 0ull) return;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int q = 0; q < 4; ++q)
+        if ((m >> (16 * q)) & 1ull)
+            tick_affine_body<RW, true>(c, wave * 4 + q, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
 }
 
 // Second launch of every tick: exits at once unless the first one deferred instances (active inequality rows).
@@ -1382,6 +1404,7 @@ struct ismpc_handle {
     int force_waves = 0;      // dense path: 4, 8 or 16 wavefronts per workgroup (0 = 16)
     unsigned char* zmark = nullptr; int zmark_cap = 0; int launch_id = 0; bool z_fallback = true;
     bool dense_path = false;  // true: per-tick MFMA solve (ismpc_tick_dense); false: affine tables (ismpc_tick_affine)
+    int cus = 0;              // compute units of the device (kernel variant selection); 0: never the one-launch variant
     bool quad_path = true;    // affine tables, four instances per wavefront (ismpc_tick_quad) where it applies; ISMPC_PATH=wave: one per wavefront
 };
 
@@ -1421,6 +1444,19 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
             const int RQ = (h->c.N + 15) / 16;
             const int waves = (batch + 3) / 4;
             const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
+            // every wavefront resident at once (<= 2 per SIMD) and a fallback to run: one launch that handles deferred instances itself
+            if (zm && h->cus > 0 && waves <= 8 * h->cus && R <= 2) {
+#define ISMPC_QUADI(RR, RW_) hipLaunchKernelGGL((ismpc_tick_quad_inline<RR, RW_>), qgrid, qblock, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid)
+#define ISMPC_QUADI2(RR) do { if (R == 1) ISMPC_QUADI(RR, 1); else ISMPC_QUADI(RR, 2); } while (0)
+                switch (RQ) {
+                    case 1: ISMPC_QUADI2(1); break; case 2: ISMPC_QUADI2(2); break; case 3: ISMPC_QUADI2(3); break; case 4: ISMPC_QUADI2(4); break;
+                    case 5: ISMPC_QUADI2(5); break; case 6: ISMPC_QUADI2(6); break; case 7: ISMPC_QUADI2(7); break; default: ISMPC_QUADI2(8); break;
+                }
+#undef ISMPC_QUADI2
+#undef ISMPC_QUADI
+                HIP_TRY(hipGetLastError());
+                return ISMPC_OK;
+            }
 #define ISMPC_QUAD(RR) hipLaunchKernelGGL(ismpc_tick_quad<RR>, qgrid, qblock, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid)
             switch (RQ) {
                 case 1: ISMPC_QUAD(1); break; case 2: ISMPC_QUAD(2); break; case 3: ISMPC_QUAD(3); break; case 4: ISMPC_QUAD(4); break;
@@ -1517,6 +1553,8 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     if (const char* zf = std::getenv("ISMPC_Z_FALLBACK")) h->z_fallback = std::atoi(zf) != 0;   // 0: flag only, no second launch
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete h; return fail(ISMPC_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
+    { hipDeviceProp_t prop; h->cus = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0; }
+    if (const char* fu = std::getenv("ISMPC_ONE_LAUNCH")) { if (std::atoi(fu) == 0) h->cus = 0; }    // 0: always two launches (A/B)
     const ismpc::Tables& t = h->t;
     DevConst& c = h->c;
     c.N = t.p.N; c.NP = t.NP; c.NPs = t.NP + 2; c.S = t.p.S; c.F = t.p.F; c.nmid = t.nmid; c.npat = t.npat;
