@@ -78,7 +78,7 @@ typedef struct ismpc_a_out {            /* 80 bytes */
     double  u0[2];                      /* predicted_xzd(1), predicted_yzd(1) */
     double  f0[2];                      /* predicted_xfs(1), predicted_yfs(1) */
     int32_t status;
-    int32_t iters_x, iters_y;           /* active-set iterations */
+    int32_t iters_x, iters_y;           /* work per QP: block warm-start passes + Goldfarb-Idnani steps (+1 for a polish solve) */
     int32_t active;                     /* final working-set sizes: x | y << 16 */
 } ismpc_a_out;
 
