@@ -337,3 +337,37 @@ def test_block_warm_start_equals_cold_start(FA, name, monkeypatch):
     a, b = q_from_dev(sw, FA.STATE_A), q_from_dev(sc, FA.STATE_A)
     assert (a["fc"] == b["fc"]).all() and (a["j"] == b["j"]).all()
     assert ow["iters_x"][ok].mean() < 0.6 * oc["iters_x"][ok].mean()               # and it does shorten the route
+
+
+def test_pushed_rollout_with_history_against_oracle(FA):
+    """Closed loop with a disturbance in the middle: 40 nominal ticks, ONE pushed tick (caller-driven, working-set history
+    switched on so that the stale guess is used and has to be repaired), 60 more ticks -- per instance against the oracle."""
+    import torch
+    from oracle import oracle_a as A
+    phi, dA = np.pi / 4, 0.1
+    g = FA.default_gait(A.WALK, phi, dA)
+    _, ce = FA.plan(g)
+    gen = FA.GaitGenerator(FA.default_params(A.WALK), ce)
+    gen.set_warm_history(True)
+    pushes = np.array([[0.03, -0.05], [-0.025, 0.04], [0.0, 0.05], [0.02, 0.0]])
+    n = len(pushes)
+    st = q_to_dev(gen.initial_state(g.disp_C, batch=n))
+    outs = []
+    for t in range(40):
+        outs.append(q_from_dev(gen.tick_torch(st), FA.OUT_A))
+    outs.append(q_from_dev(gen.tick_torch(st, torch.from_numpy(pushes.copy()).to("cuda:0")), FA.OUT_A))
+    for t in range(60):
+        outs.append(q_from_dev(gen.tick_torch(st), FA.OUT_A))
+    torch.cuda.synchronize()
+    out = np.stack(outs)                                                            # [101, n]
+    assert (out["status"] == 0).all()
+    for i in range(n):
+        sim = A.SimA(A.gait(A.WALK, phi, dA), A.params(A.WALK), backend="gi")
+        ref = list(sim.run(40)) + [sim.tick(tuple(pushes[i]))] + list(sim.run(60))
+        rc = np.array([r["com_before"] for r in ref]); ru = np.array([r["u0"] for r in ref]); rf = np.array([r["f0"] for r in ref])
+        assert np.abs(out["com_before"][:, i] - rc).max() <= 1e-6 * max(1.0, np.abs(rc).max()), i
+        assert np.abs(out["u0"][:, i] - ru).max() <= 1e-6 * max(1.0, np.abs(ru).max()), i
+        assert np.abs(out["f0"][:, i] - rf).max() <= 1e-7, i
+    # the history does its job: the typical QP of the loop costs a few passes (step changes and the push cost more)
+    both = np.concatenate([out["iters_x"].ravel(), out["iters_y"].ravel()])
+    assert np.median(both) <= 4
