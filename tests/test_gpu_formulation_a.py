@@ -371,3 +371,24 @@ def test_pushed_rollout_with_history_against_oracle(FA):
     # the history does its job: the typical QP of the loop costs a few passes (step changes and the push cost more)
     both = np.concatenate([out["iters_x"].ravel(), out["iters_y"].ravel()])
     assert np.median(both) <= 4
+
+
+def test_full_batch_is_bitwise_reproducible(FA):
+    """Work is claimed dynamically (any wavefront may solve any QP, in any order), results must not depend on it:
+    16 384 pushed instances twice, byte-identical outputs and states."""
+    import torch
+    z = np.load(os.path.join(GOLDEN, "prerollA_walk_C150.npz"))
+    tab = z["state"].view(FA.STATE_A).reshape(-1)
+    kind = int(z["gait"]); g = FA.default_gait(kind, float(z["phi"]), float(z["disp_A"]))
+    _, ce = FA.plan(g)
+    gen = FA.GaitGenerator(FA.default_params(kind, C=int(z["C"]), P=int(z["P"]), F=int(z["F"])), ce)
+    rng = np.random.default_rng(4)
+    B = 16384
+    st0 = tab[rng.integers(0, len(tab), B)].copy()
+    push = torch.from_numpy(np.stack([rng.uniform(-0.03, 0.03, B), rng.uniform(-0.05, 0.05, B)], 1)).to("cuda:0")
+    s1, s2 = q_to_dev(st0), q_to_dev(st0)
+    o1 = gen.tick_torch(s1, push); o2 = gen.tick_torch(s2, push)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(s1, s2)
+    o = q_from_dev(o1, FA.OUT_A)
+    assert (o["status"] == 0).all()
