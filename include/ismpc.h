@@ -125,7 +125,10 @@ int ismpc_solve_batch(ismpc_handle* h, int batch,
 /* Same, device pointers, enqueued on `stream` (a hipStream_t; NULL = the
  * default stream), asynchronous.  `u_traj` is NULL or a device buffer of
  * batch x 3 x N doubles receiving the three decision trajectories
- * (decisionVariables_z/_x/_y, MPCSolver.cpp:269,395,396).                   */
+ * (decisionVariables_z/_x/_y, MPCSolver.cpp:269,395,396).
+ * A handle owns scratch that its launches share (the per-instance marks of the
+ * inequality fallback): launches of ONE handle must be ordered -- one stream, or
+ * streams synchronised by the caller.  Independent handles are independent.  */
 int ismpc_solve_batch_device(ismpc_handle* h, int batch,
                              const ismpc_tick_in* in_dev, ismpc_tick_out* out_dev,
                              double* u_traj, void* stream);

@@ -17,7 +17,8 @@
  *
  * The swing-foot re-placement QPs, the foot trajectories and the text wire format are the
  * ismpc_a_*feet* / ismpc_a_foot_trajectories / ismpc_a_write_trajectory_txt entry points further down.
- * Conventions as ismpc.h: plain C, int status, no CPU fallback.
+ * Conventions as ismpc.h: plain C, int status, no CPU fallback; launches of one handle must be ordered (the handle owns
+ * the copy of the previous state, the work counter and the working-set history that its launches share).
  */
 #ifndef ISMPC_A_H
 #define ISMPC_A_H
