@@ -545,7 +545,6 @@ void ismpc_a_tick_kernel(const DevA c, const ismpc_a_state* __restrict__ state_i
 // termination are Goldfarb-Idnani's.  Lanes own RL consecutive rows (row = ZMP sample), so the primal direction is
 // "own multiplier as an impulse + one suffix scan" with no scatter; wave collectives are DPP scans / min / max.
 // =====================================================================================================
-constexpr int MAXM = 2 * MAXF + 1;
 // Per-wavefront LDS.  Small vectors (length m = 2F+1 or F+2) are kept ONE ELEMENT PER LANE in registers and mirrored
 // here when other lanes need them by index; nothing of size "working set" is stored anywhere.
 template <int F> struct WaveLds {
@@ -563,14 +562,6 @@ template <int F> struct WaveLds {
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 template <int CTRL, int RM> __device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xf, false); }
-__device__ __forceinline__ int wave_max_i(int v)
-{
-    const int lo = -2147483647 - 1;
-    v = max(v, dpp_i<0x111, 0xf>(lo, v)); v = max(v, dpp_i<0x112, 0xf>(lo, v)); v = max(v, dpp_i<0x114, 0xf>(lo, v));
-    v = max(v, dpp_i<0x118, 0xf>(lo, v)); v = max(v, dpp_i<0x142, 0xa>(lo, v)); v = max(v, dpp_i<0x143, 0xc>(lo, v));
-    return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ int wave_min_i(int v) { return -wave_max_i(-v); }
 __device__ __forceinline__ int wave_scan_max_i(int v)      // inclusive prefix maximum over the 64 lanes
 {
     const int lo = -2147483647 - 1;
