@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- ISMPC tick throughput on MI355X (see the contract in DESIGN.md section "Measurement").
+"""bench.py -- ISMPC tick throughput on MI355X (contract: DESIGN.md section 5 "Measurement").
 
-One "step" = one pass of the hot path (one MPCSolver::solve tick, reference MPCSolver.cpp:204-430)
-over one batch of synthetic instances already resident in HBM.  Per-GPU work is fixed (weak
-scaling): each rank owns a contiguous shard of `--batch-per-gpu` instances (default 8 192 = the
-shard of BASELINE config 3, 65 536 instances over 8 GPUs); with more than one rank a step ends with
-the single RCCL all-gather of the 80-byte output records the north star prescribes.
+One "step" = one pass of the hot path over one batch of synthetic instances already resident in HBM.
+
+Headline (the JSON line itself): Formulation B = MPCSolver::solve (reference MPCSolver.cpp:204-430), N = 100, fp64,
+GLOBAL batch 65 536 (BASELINE configs[2]).  `--gpus N` shards that batch over N ranks (strong scaling: N = 1 runs all
+65 536 instances on one GPU, N = 8 runs 8 192 per GPU); with more than one rank a step ends with the single RCCL
+all-gather of the 80-byte output records, issued on a side stream so that it overlaps the next step's kernel.
+
+`other_configs` (always emitted at N = 1): BASELINE configs[1] (1 024 instances, Formulation B), configs[3] (walking gait,
+Formulation A, C = 150, 16 384 instances) and the per-GPU shape of configs[4] (Monte-Carlo trot/walk, C = 200, 16 384
+instances per GPU), each with its own roofline and cpu_baseline.  At N > 1 configs[4] runs 16 384 instances on every
+rank (131 072 at N = 8) with the same all-gather.
 
     python bench.py                       # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.
+Timing: W warm-up steps, then regions of EXACTLY K steps each, bracketed by barrier + synchronize on both sides, wall time
+= max over ranks; regions repeat until at least --min-region-ms of timed work exists (K = 20 steps of a 56 us kernel is
+1 ms) and the MEDIAN region is reported.  Rank 0 prints ONE JSON line.
+
+cpu_baseline: the CPU oracle with the reference's own vendored qpOASES (oracle/_ref) on the box's host cores, in worker
+processes that never touch the GPU (`bench.py --cpu-worker ...`).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -25,247 +38,592 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_FP64_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD spec; MI355X_MICROARCH.md lists the FP32 157.3)
+PEAK_FP64_TFLOPS = 78.6      # MI355X FP64 vector = matrix peak (AMD spec)
+PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md
+CLOCK_GHZ = 2.4              # MI355X_MICROARCH.md "Max clock"
+SIMDS = 256 * 4
+PROFILES = os.path.join(ROOT, "profiles", "r02")
+GLOBAL_BATCH = 65536
 HORIZON = 100
+A_BATCH = 16384
 
 
-def algorithmic_flops_per_tick(N):
-    """SURVEY.md 8d, vertical Hessian factor shared by the batch: 6 N^2 + 20 N."""
+# ======================================================================================================================
+# CPU worker (test infrastructure on the host cores; never imports torch, never touches the GPU)
+# ======================================================================================================================
+def cpu_worker(spec):
+    """spec: dict(leg, n, offset, cpu).  Solves n units of the leg's workload with the oracle, prints {"n", "seconds"}."""
+    if spec.get("cpu") is not None:
+        try:
+            os.sched_setaffinity(0, {int(spec["cpu"])})
+        except OSError:
+            pass
+    leg, n, off = spec["leg"], int(spec["n"]), int(spec["offset"])
+    from quadruped_gait_generation_ismpc_amd import workload
+    if leg == "B":
+        from oracle import oracle as O
+        N = int(spec.get("horizon", HORIZON))
+        tin = workload.make_batch(N, n, first_instance=off)
+        orc = O.Oracle(O.default_params(N), backend="ref" if O.have_ref() else "gi")
+        orc.solve(tin[:2])
+        t0 = time.perf_counter(); orc.solve(tin); dt = time.perf_counter() - t0
+        done = n
+    elif leg.startswith("A:"):
+        from oracle import oracle_a as A
+        name = leg[2:]
+        backend = "ref" if A.O.have_ref() else "gi"
+        if name == "mc_C200":
+            inst, push = workload.make_inst_mc(off + n)
+            phi, dA = np.pi / 4, 0.1
+            t0 = time.perf_counter(); done = 0
+            for i in range(off, off + n):
+                kind = A.TROT if inst["plan"][i] == 0 else A.WALK
+                p = A.params(kind, C_=200, P=400, F=int(inst["F"][i]), step=int(inst["step"][i]), ds=int(inst["ds"][i]), Qf=float(inst["Qf"][i]))
+                p.height = float(inst["height"][i])
+                sim = A.SimA(A.gait(kind, phi, dA), p, backend=backend)
+                sim.run(MC_PREROLL); sim.tick(tuple(push[i])); done += MC_PREROLL + 1
+            dt = time.perf_counter() - t0
+        else:
+            w = workload.make_batch_a(name, off + n)
+            sim = A.SimA(A.gait(w["kind"], w["phi"], w["disp_A"]), A.params(w["kind"], C_=w["C"], P=w["P"], F=w["F"]), backend=backend)
+            t0 = time.perf_counter()
+            for i in range(off, off + n):
+                sim.load_product_state(w["state"][i]); sim.tick(tuple(w["push"][i]))
+            dt = time.perf_counter() - t0; done = n
+    else:
+        raise SystemExit(f"unknown cpu leg {leg}")
+    print(json.dumps({"n": done, "seconds": dt}), flush=True)
+
+
+MC_PREROLL = 60      # nominal closed-loop ticks that spread the gait phases of the Monte-Carlo instances before the timed tick
+
+
+def _spawn_worker(spec):
+    return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", json.dumps(spec)], cwd=ROOT,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, close_fds=True)
+
+
+def _collect(procs, timeout):
+    res = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill(); o, e = p.communicate()
+        line = [l for l in o.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            raise RuntimeError("cpu worker failed: " + (e or "")[-500:])
+        res.append(json.loads(line[-1]))
+    return res
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                model = l.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = list(range(os.cpu_count() or 1))
+    return model, os.cpu_count(), aff
+
+
+def cpu_baseline(leg, unit, budget_s, sample_desc, unit_per_n=1, horizon=HORIZON):
+    """The oracle (reference qpOASES backend where oracle/_ref exists) timed on this box's host cores: one pinned core
+    (`value`, `cores` = 1) and, beside it, the embarrassingly parallel figure on all cores of this process's CPU share
+    (`all_cores`).  Bounded samples of the same workload, about `budget_s` seconds each."""
+    from oracle import oracle as O
+    kind = "reference" if O.have_ref() else "port"
+    model, nproc, aff = cpu_info()
+    share = aff[:16]                                         # the GPU box grants 16 CPUs per GPU; never oversubscribe
+    probe_n = 1 if leg == "A:mc_C200" else 24
+    pr = _collect([_spawn_worker(dict(leg=leg, n=probe_n, offset=0, cpu=share[0], horizon=horizon))], 600)[0]
+    per = pr["seconds"] / max(pr["n"], 1) * unit_per_n      # seconds per worker item (instance)
+    n1 = int(max(probe_n, min(4096, budget_s / max(per, 1e-6))))
+    one = _collect([_spawn_worker(dict(leg=leg, n=n1, offset=0, cpu=share[0], horizon=horizon))], 900)[0]
+    single = one["n"] / one["seconds"]
+    allc = _collect([_spawn_worker(dict(leg=leg, n=n1, offset=0, cpu=c, horizon=horizon)) for c in share], 1800)
+    multi = sum(r["n"] / r["seconds"] for r in allc)
+    qp = "reference vendored qpOASES 3.2 (setToMPC, nWSR=300, cold init per QP)" if kind == "reference" else "oracle Goldfarb-Idnani"
+    return {"value": single, "unit": unit, "cores": 1, "kind": kind,
+            "sample": f"{sample_desc}: {one['n']} {unit.split('/')[0]} in {one['seconds']:.1f} s on one pinned core, {qp}",
+            "ms_per_unit": 1e3 / single,
+            "all_cores": {"value": multi, "cores": len(share), "note": "one pinned worker process per core, same sample each, rates summed"},
+            "cpu_model": model, "nproc": nproc, "cpus_in_share": len(aff)}
+
+
+# ======================================================================================================================
+# GPU side
+# ======================================================================================================================
+class Ranks:
+    def __init__(self, gpus):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != gpus and self.world == 1 and gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        assert torch.cuda.is_available(), "bench.py needs an MI355X: the hot path has no CPU fallback"
+        # ISMPC_BENCH_REHEARSE=1: rehearsal of the multi-rank control flow on a ONE-GPU box -- every rank uses cuda:0 and the
+        # all-gather runs over gloo on host copies.  Not a measurement (the JSON line says so); the driver never sets it.
+        self.rehearse = self.world > 1 and os.environ.get("ISMPC_BENCH_REHEARSE") == "1"
+        if self.rehearse:
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.rehearse:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)   # "nccl" is RCCL on ROCm
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=("cpu" if self.rehearse else self.dev))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def timed_regions(R, step, K, W, min_ms, drain=None, ev=None):
+    """W warm-up steps; then regions of exactly K steps, barrier + synchronize on both sides, max over ranks; regions repeat
+    until min_ms of timed work (at least 3).  ev = (record_start, record_end) hooks on the launch stream, per region."""
+    torch = R.torch
+    for k in range(W):
+        step(k)
+    if drain:
+        drain()
+    walls, n = [], 0
+    total = 0.0
+    while True:
+        R.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        if ev:
+            ev[0](n)
+        for k in range(K):
+            step(k)
+        if ev:
+            ev[1](n)
+        if drain:
+            drain()
+        torch.cuda.synchronize(); R.barrier()
+        el = R.max(time.perf_counter() - t0)
+        walls.append(el); total += el; n += 1
+        if (n >= 3 and total >= min_ms * 1e-3) or n >= 400:
+            break
+    return walls
+
+
+class RegionEvents:
+    """One HIP-event pair per region on torch's current stream -- which IS the stream the C ABI launches on."""
+    def __init__(self, torch):
+        self.torch, self.pairs = torch, []
+
+    def start(self, n):
+        a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        self.pairs.append((a, b)); a.record()
+
+    def end(self, n):
+        self.pairs[n][1].record()
+
+    def median_ms(self, K):
+        return statistics.median(a.elapsed_time(b) for a, b in self.pairs) / K
+
+
+def load_pmc(leg):
+    """profiles/r02/pmc_<leg>.json (scripts/profile_r02.sh + scripts/pmc_summary.py): counters of the dominant kernel,
+    mean per launch, collected on exactly this leg's batch -- never scaled from another batch."""
+    path = os.path.join(PROFILES, f"pmc_{leg}.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))
+    except ValueError:
+        return None
+
+
+def executed_work(leg, kernel, kernel_ms, batch):
+    """What the kernel executes, from the committed PMC pass of this leg: VALU instructions per launch x 4 cycles (one
+    wave64 FP64 instruction occupies the 16-lane pipe for 4 cycles) / 1 024 SIMDs / 2.4 GHz = the time the vector pipes
+    are issuing, over the measured kernel time; HBM bytes per launch (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE)."""
+    j = load_pmc(leg)
+    if not j or j.get("batch") != batch or j.get("kernel", "") not in kernel:
+        return None, None
+    c = j.get("counters_mean_per_launch", {})
+    ex = None
+    if "SQ_INSTS_VALU" in c:
+        issue_ms = c["SQ_INSTS_VALU"] * 4.0 / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
+        ex = {"valu_insts_per_launch": c["SQ_INSTS_VALU"], "valu_issue_ms": issue_ms, "valu_issue_frac": issue_ms / kernel_ms,
+              "mfma_insts_per_launch": c.get("SQ_INSTS_VALU_MFMA_F64", 0.0) if "SQ_INSTS_VALU_MFMA_F64" in c else None,
+              "source": f"profiles/r02/pmc_{leg}.json"}
+    return ex, j.get("derived", {}).get("hbm_bytes_per_launch")
+
+
+def flops_b(N):
+    """SURVEY.md 8d, vertical Hessian factor shared by the batch: 6 N^2 + 20 N per tick."""
     return 6.0 * N * N + 20.0 * N
 
 
-def measured_traffic(N, B):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_quad_b8192.json:
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads, + WRITE_SIZE), scaled by
-    instances per launch; None when no profile of this kernel/horizon is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_quad_b8192.json")
-    if not os.path.exists(path) or os.environ.get("ISMPC_PATH") == "dense":
-        return None
-    j = json.load(open(path))
-    if j.get("horizon") != N:
-        return None
-    return j["derived"]["hbm_bytes_per_launch"] * B / j["batch"]
+def flops_a(C, F, w):
+    """flops_A = 2 [nv w^2 + w^3/3 + 4 nv w + 6 nv], nv = C + F_A, w = measured mean working-set size."""
+    nv = C + F
+    return 2.0 * (nv * w * w + w ** 3 / 3.0 + 4.0 * nv * w + 6.0 * nv)
 
 
 def one_launch(N, B, cus):
-    """csrc/ismpc_hip.hip launch(): batches whose wavefronts are all resident at once (<= 2 per SIMD) take the variant that
-    runs the inequality fallback inside the same launch."""
+    """csrc/ismpc_hip.hip launch(): does a step of batch B consist of ONE kernel launch?"""
     path = os.environ.get("ISMPC_PATH")
-    return (path not in ("dense", "wave") and N <= 128 and os.environ.get("ISMPC_ONE_LAUNCH") != "0"
-            and os.environ.get("ISMPC_Z_FALLBACK") != "0" and (B + 3) // 4 <= 8 * cus)
+    if path == "dense" or os.environ.get("ISMPC_Z_FALLBACK") == "0":
+        return True
+    return (path != "wave" and N <= 128 and os.environ.get("ISMPC_ONE_LAUNCH") != "0" and (B + 3) // 4 <= 8 * cus)
 
 
-def kernel_name(N, B, cus):
-    """The dominant kernel of the step, as rocprofv3 names it (csrc/ismpc_hip.hip launch())."""
+def kernel_name_b(N, B, cus):
     path = os.environ.get("ISMPC_PATH")
     if path == "dense":
         return "ismpc_tick_dense<%d, 16>" % ((N + 63) // 64)
     if path == "wave" or N > 128:
         return "ismpc_tick_affine<%d>" % ((N + 63) // 64)
-    if one_launch(N, B, cus):
+    if one_launch(N, B, cus) and os.environ.get("ISMPC_Z_FALLBACK") != "0":
         return "ismpc_tick_quad_inline<%d, %d>" % ((N + 15) // 16, (N + 63) // 64)
-    return "ismpc_tick_quad<%d>" % ((N + 15) // 16)        # four instances per wavefront
+    return "ismpc_tick_quad<%d>" % ((N + 15) // 16)
 
 
-def cpu_baseline(N, tick_in, budget_s=20.0):
-    """The reference's single-thread qpOASES path on this box's host cores: the CPU restatement of
-    MPCSolver::solve with every QP solved by the reference's own vendored qpOASES (oracle/_ref),
-    cold start per QP exactly like utils.cpp:121-130.  Bounded sample of the same workload."""
-    from oracle import oracle as O
-    kind = "reference" if O.have_ref() else "port"
-    orc = O.Oracle(O.default_params(N), backend="ref" if kind == "reference" else "gi")
-    orc.solve(tick_in[:8])                       # warm-up
-    t0 = time.perf_counter(); orc.solve(tick_in[:64]); per = (time.perf_counter() - t0) / 64
-    n = int(max(64, min(len(tick_in), budget_s / max(per, 1e-6))))
-    t0 = time.perf_counter()
-    out, info = orc.solve(tick_in[:n])
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "ticks/s", "cores": 1, "kind": kind,
-            "sample": f"first {n} instances of the same batch, {dt:.1f} s, single thread, "
-                      f"{'reference vendored qpOASES 3.2 (setToMPC, nWSR=300, cold init per QP)' if kind == 'reference' else 'oracle Goldfarb-Idnani'}",
-            "ms_per_tick": 1e3 * dt / n}
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch-per-gpu", type=int, default=8192)
-    ap.add_argument("--horizon", type=int, default=HORIZON)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--also-config1", action="store_true",
-                    help="additionally time BASELINE configs[1] (1 024 instances, one GPU) and report it under other_configs; "
-                         "off by default so that a rocprofv3 summary of the default command holds launches of one size only")
-    args = ap.parse_args()
-
-    import torch
-    import quadruped_gait_generation_ismpc_amd as q
+def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
+    """Formulation B: `global_batch` instances sharded over the ranks; returns the result dict (rank 0) or None."""
+    torch = R.torch
     from quadruped_gait_generation_ismpc_amd import workload
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs an MI355X: the hot path has no CPU fallback"
-    # ISMPC_BENCH_REHEARSE=1: rehearsal of the multi-rank control flow on a ONE-GPU box -- every rank uses cuda:0 and the
-    # all-gather runs over gloo on host copies.  Not a measurement (the JSON line says so); the driver never sets it.
-    rehearse = world > 1 and os.environ.get("ISMPC_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
-
-    from quadruped_gait_generation_ismpc_amd.distributed import shard_range, gather_records
-    N, B = args.horizon, args.batch_per_gpu
-    first, count = shard_range(world * B, rank, world)
-    assert (first, count) == (rank * B, B)
-    counts = [B] * world
+    from quadruped_gait_generation_ismpc_amd.distributed import shard_range, GatherPipeline
+    world, rank = R.world, R.rank
+    first, B = shard_range(global_batch, rank, world)
+    assert global_batch % world == 0, "the bench shards the global batch evenly"
     p = q.default_params(N=N)
-    solver = q.MPCSolver(q.reference_plan(params=p), params=p, device=local_rank)
-    tick_in = workload.make_batch(N, B, first_instance=rank * B)         # this rank's shard, no communication
-    d_in = q.to_device(tick_in, dev)
-    d_out = torch.empty((B, 80), dtype=torch.uint8, device=dev)
-    d_all = torch.empty((world * B, 80), dtype=torch.uint8, device=("cpu" if rehearse else dev)) if world > 1 else None
-    _gather = gather_records
-    if rehearse:
-        def gather_records(local, world_, out=None, counts=None):          # host copies over gloo
-            return _gather(local.cpu(), world_, out=out, counts=counts)
+    solver = q.MPCSolver(q.reference_plan(params=p), params=p, device=R.local_rank)
+    tick_in = workload.make_batch(N, B, first_instance=first)            # this rank's shard, no communication
+    d_in = q.to_device(tick_in, R.dev)
+    d_out = [torch.empty((B, 80), dtype=torch.uint8, device=R.dev) for _ in range(2)]
+    cus = torch.cuda.get_device_properties(R.dev).multi_processor_count
+    pipe = None
+    if world > 1:
+        pipe = GatherPipeline(world, B, 80, device=("cpu" if R.rehearse else R.dev), host_copies=R.rehearse)
 
-    def step():
-        solver.solve_batch_torch(d_in, d_out)
-        if world > 1:
-            gather_records(d_out, world, out=d_all, counts=counts)        # the one collective of the path
+    def step(k):
+        if pipe is None:
+            solver.solve_batch_torch(d_in, d_out[0])
+        else:
+            b = pipe.before_launch(k)                                    # gather k-2 has left d_out[b]
+            solver.solve_batch_torch(d_in, d_out[b])
+            pipe.after_launch(k, d_out[b])                               # the one collective of the path, on the side stream
 
-    for _ in range(args.warmup):
-        step()
-    # Kernel duration for the roofline: HIP events on the launch stream (torch's current stream IS the stream
-    # the C ABI launches on).  An event pair around a ~10 us kernel reads several us high, so on one GPU the
-    # pair brackets the whole timed region (K back-to-back launches, nothing else on the stream) and the
-    # average launch interval is reported; with a collective in the loop each launch gets its own pair.
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    ev_region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if world == 1:
-        ev_region[0].record()
-        for k in range(args.steps):
-            solver.solve_batch_torch(d_in, d_out)
-        ev_region[1].record()
-    else:
-        for k in range(args.steps):
-            ev[k][0].record()
-            solver.solve_batch_torch(d_in, d_out)
-            ev[k][1].record()
-            gather_records(d_out, world, out=d_all, counts=counts)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=("cpu" if rehearse else dev))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    step_interval_ms = None
-    if world == 1:
-        # Small batches: the step is ONE launch (ismpc_tick_quad_inline) and the region above already times it.  Large
-        # batches: two launches (ismpc_tick_quad, then the normally idle inequality fallback); the roofline then prices the
-        # dominant kernel alone: same inputs, same kernel, a handle created with the fallback launch switched off
-        # (ISMPC_Z_FALLBACK=0), K back-to-back launches bracketed by one event pair on the launch stream.
-        step_interval_ms = ev_region[0].elapsed_time(ev_region[1]) / args.steps
-        kernel_ms = step_interval_ms
-        cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        if one_launch(N, B, cus):
-            pass                                          # the step IS one launch of the dominant kernel
-        elif os.environ.get("ISMPC_PATH") != "dense" and os.environ.get("ISMPC_Z_FALLBACK") != "0":
-            os.environ["ISMPC_Z_FALLBACK"] = "0"
+    ev = RegionEvents(torch)
+    walls = timed_regions(R, step, K, W, min_ms, drain=(pipe.drain if pipe else None), ev=(ev.start, ev.end))
+    wall = statistics.median(walls)
+    step_interval_ms = ev.median_ms(K)
+
+    # ---- dominant kernel alone (roofline): same inputs, K back-to-back launches bracketed by one event pair per region
+    kernel_ms = step_interval_ms
+    if world > 1 or not one_launch(N, B, cus):
+        solo = solver
+        if not one_launch(N, B, cus):
+            os.environ["ISMPC_Z_FALLBACK"] = "0"                         # the normally idle second launch switched off
             try:
-                solo = q.MPCSolver(q.reference_plan(params=p), params=p, device=local_rank)
+                solo = q.MPCSolver(q.reference_plan(params=p), params=p, device=R.local_rank)
             finally:
                 del os.environ["ISMPC_Z_FALLBACK"]
-            d_tmp = torch.empty_like(d_out)
-            for _ in range(args.warmup):
-                solo.solve_batch_torch(d_in, d_tmp)
-            torch.cuda.synchronize()
-            ev_region[0].record()
-            for _ in range(args.steps):
-                solo.solve_batch_torch(d_in, d_tmp)
-            ev_region[1].record()
-            torch.cuda.synchronize()
-            kernel_ms = ev_region[0].elapsed_time(ev_region[1]) / args.steps
-    else:
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        d_tmp = torch.empty_like(d_out[0])
+        ev2 = RegionEvents(torch)
+        timed_regions(R, lambda k: solo.solve_batch_torch(d_in, d_tmp), K, W, min_ms, ev=(ev2.start, ev2.end))
+        kernel_ms = ev2.median_ms(K)
+    collective_ms = None
+    if pipe is not None:
+        ev3 = RegionEvents(torch)
+        timed_regions(R, lambda k: pipe.gather_blocking(d_out[0]), K, W, min_ms, ev=(ev3.start, ev3.end))
+        collective_ms = ev3.median_ms(K) if not R.rehearse else None
 
-    # BASELINE configs[1] (1 024 instances on one GPU) beside the headline shard: same kernels, same inputs (first 1 024)
-    small = None
-    if world == 1 and B > 1024 and args.also_config1:
-        d_in_s, d_out_s = d_in[:1024].contiguous(), torch.empty((1024, 80), dtype=torch.uint8, device=dev)
-        for _ in range(args.warmup):
-            solver.solve_batch_torch(d_in_s, d_out_s)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); ts = time.perf_counter(); e0.record()
-        for _ in range(args.steps):
-            solver.solve_batch_torch(d_in_s, d_out_s)
-        e1.record(); torch.cuda.synchronize(); el_s = time.perf_counter() - ts
-        k_ms = e0.elapsed_time(e1) / args.steps
-        small = {"workload": "BASELINE configs[1]: 1 024 instances, N=%d, one GPU" % N, "value": 1024 * args.steps / el_s, "unit": "ticks/s",
-                 "ms_per_step": 1e3 * el_s / args.steps, "kernel_ms": k_ms,
-                 "roofline_frac": algorithmic_flops_per_tick(N) * 1024 / (k_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS}
-
-    out = q.from_device(d_out, q.TICK_OUT)
-    if world > 1:
-        allout = q.from_device(d_all, q.TICK_OUT) if not rehearse else np.frombuffer(d_all.numpy().tobytes(), dtype=q.TICK_OUT)
-        assert allout[rank * B:(rank + 1) * B].tobytes() == out.tobytes(), "all-gather misplaced this rank's shard"
+    out = q.from_device(d_out[0], q.TICK_OUT)
+    if pipe is not None:
+        allout = pipe.result_numpy((K - 1) & 1, q.TICK_OUT)
+        assert allout[rank * B:(rank + 1) * B].tobytes() == q.from_device(d_out[(K - 1) & 1], q.TICK_OUT).tobytes(), "all-gather misplaced this rank's shard"
     st = out["status"]
-    frac_flight = float(((st & q.ST_FLIGHT) != 0).mean())
-    frac_infeasible = float(((st & (q.ST_X_INFEASIBLE | q.ST_Y_INFEASIBLE)) != 0).mean())
+    stage3 = (st & (q.ST_FLIGHT | q.ST_BAD_INDEX | q.ST_TICK_SKIPPED)) == 0
+    itx, ity = out["iters"] & 255, (out["iters"] >> 8) & 255
+    nqp = 2 * int(stage3.sum())
+    active_box = (int(((itx >= 2) & stage3).sum()) + int(((ity >= 2) & stage3).sum())) / max(nqp, 1)
 
+    res = None
     if rank == 0:
-        ticks = world * B * args.steps
-        value = ticks / elapsed
-        flops = algorithmic_flops_per_tick(N) * B
+        value = global_batch / (wall / K)
+        flops = flops_b(N) * B
         achieved = flops / (kernel_ms * 1e-3) / 1e12
-        line = {
-            "metric": "ISMPC QP solves/s (batch, N=100 horizon)", "value": value,
-            "unit": "ticks/s (1 tick = one MPCSolver::solve = 3 QPs: vertical + x + y)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
-            "config": {"workload": f"Formulation B (MPCSolver::solve), trot plan Controller.cpp:89-97, N={N}, S=35, F=10, "
-                                   f"{B} instances/GPU (shard of BASELINE config 3: 65 536 over 8 GPUs), nominal pre-roll + perturbation (SURVEY 8d)",
-                       "horizon": N, "batch_per_gpu": B, "global_batch": world * B,
-                       "collective": "one RCCL all-gather of 80-byte output records per step" if world > 1 else "none (1 GPU)",
-                       "flight_fraction": frac_flight, "infeasible_fraction": frac_infeasible},
-            "qp_solves_per_s": 3.0 * value,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": measured_traffic(N, B),
-                         "kernel": kernel_name(N, B, torch.cuda.get_device_properties(dev).multi_processor_count), "kernel_ms": kernel_ms, "step_interval_ms": step_interval_ms,
-                         "algorithmic_flops_per_launch": flops,
-                         "note": "FP64 compute roofline (vector = matrix peak 78.6 TF); algorithmic flops 6N^2+20N per tick, "
-                                 "shared vertical factor; algorithmic HBM bytes 152 B/tick are ~1e-4 of the HBM roofline; "
-                                 "traffic = HBM bytes/launch from rocprofv3 PMC (profiles/r01/pmc_quad_b8192.json), "
-                                 "measured at 8192 instances/launch and scaled linearly to this batch"},
+        kname = kernel_name_b(N, B, cus)
+        executed, traffic = executed_work(leg, kname, kernel_ms, B)
+        res = {
+            "value": value, "unit": "ticks/s (1 tick = one MPCSolver::solve = 3 QPs: vertical + x + y)",
+            "ms_per_step": 1e3 * wall / K, "dtype": "f64", "qp_solves_per_s": 3.0 * value,
+            "regions": len(walls), "region_ms": {"median": 1e3 * wall, "min": 1e3 * min(walls), "max": 1e3 * max(walls)},
+            "config": {"workload": f"Formulation B (MPCSolver::solve), trot plan Controller.cpp:89-97, N={N}, S=35, F=10, fp64, "
+                                   f"global batch {global_batch} ({B} instances/GPU), nominal pre-roll + perturbation (SURVEY 8d)",
+                       "horizon": N, "global_batch": global_batch, "batch_per_gpu": B,
+                       "collective": ("one RCCL all-gather of 80-byte output records per step, side stream, double-buffered "
+                                      "(overlaps the next step's kernel)") if world > 1 else "none (1 GPU)",
+                       "flight_fraction": float(((st & q.ST_FLIGHT) != 0).mean()),
+                       "infeasible_fraction": float(((st & (q.ST_X_INFEASIBLE | q.ST_Y_INFEASIBLE)) != 0).mean()),
+                       "z_inequality_active_fraction": float(((st & q.ST_Z_INEQ_ACTIVE) != 0).mean()),
+                       "active_box_fraction": active_box},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "kernel": kname, "kernel_ms": kernel_ms, "step_interval_ms": step_interval_ms,
+                         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": 152.0 * B,
+                         "executed": executed,
+                         "note": "bound: FP64 VECTOR issue (the kernel issues no MFMA; MI355X FP64 vector peak = matrix peak = 78.6 TF, which "
+                                 "is the number the contract's 'mfma' slot would hold).  achieved / frac = ALGORITHMIC credit per SURVEY 8d "
+                                 "(6N^2+20N flop per tick: the reference's dense vertical solve with a batch-shared factor) / kernel_ms -- the "
+                                 "kernel evaluates that solve from affine tables, so frac is not pipe utilisation and grows with batch; "
+                                 "executed.valu_issue_frac is: measured VALU instructions x 4 cycles / 1024 SIMDs / 2.4 GHz / kernel_ms.  "
+                                 "traffic = HBM bytes per launch from the PMC pass of this batch (algorithmic: 152 B/tick, ~1e-4 of the HBM roofline)"},
         }
-        if small is not None:
-            line["other_configs"] = [small]
+        if collective_ms is not None or world > 1:
+            res["multi_gpu"] = {"kernel_ms": kernel_ms, "collective_ms": collective_ms, "overlapped_step_ms": 1e3 * wall / K}
+        if extras and world == 1:
+            # PCIe-inclusive rate through the host-pointer entry point (pageable numpy buffers in and out) -- never `value`
+            solver.solve_batch(tick_in[:64])
+            reps = max(3, int(0.05 / max(1e-4, B * 2.5e-9 + 1e-4)))
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                solver.solve_batch(tick_in)
+            el = time.perf_counter() - t0
+            res["value_incl_pcie"] = B * reps / el
+            res["ms_per_step_incl_pcie"] = 1e3 * el / reps
+            # batch of ONE through ismpc_solve_batch = the body of MPCSolver::solve in include/MPCSolver.hpp (Controller.cpp:346-348 shape)
+            import ctypes as C
+            one_in = np.ascontiguousarray(tick_in[:1]); one_out = np.zeros(1, dtype=q.TICK_OUT)
+            pi, po = one_in.ctypes.data_as(C.c_void_p), one_out.ctypes.data_as(C.c_void_p)
+            lat = []
+            for k in range(320):
+                t0 = time.perf_counter()
+                rc = solver._lib.ismpc_solve_batch(solver._h, 1, pi, po)
+                lat.append(time.perf_counter() - t0)
+                assert rc == 0
+            lat = sorted(lat[20:])
+            res["latency_batch1_us"] = 1e6 * lat[len(lat) // 2]
+            res["latency_batch1_us_p99"] = 1e6 * lat[int(0.99 * len(lat))]
+    solver.close()
+    return res
+
+
+def a_kernel_name(C, F, per_inst, dtype):
+    rl = max(2, (C + 63) // 64)
+    pi = "true" if per_inst else "false"
+    return f"ismpc_a_tick_wave<{rl}, {F}, {pi}>"
+
+
+def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
+    """Formulation A: `batch` instances PER RANK (weak: every rank draws its own instances); one tick per step from the
+    same pushed states (state restored by a device copy inside the step, as a caller replaying a Monte-Carlo draw does)."""
+    torch = R.torch
+    from quadruped_gait_generation_ismpc_amd import formulation_a as FA, workload
+    from quadruped_gait_generation_ismpc_amd.distributed import gather_records
+    world, rank = R.world, R.rank
+    prec = {"f64": None, "f32": "f32"}[dtype]
+    kw = {} if prec is None else {"precision": prec}
+    if name == "mc_C200":
+        Cn, Pn, Fn = 200, 400, 6
+        inst, push = workload.make_inst_mc(batch, stream=rank)
+        plans = [FA.plan(FA.default_gait(k, np.pi / 4, 0.1))[1] for k in (0, 1)]
+        gen = FA.GaitGenerator(FA.default_params(0, C=Cn, P=Pn, F=Fn), plans[0], device=R.local_rank, **kw); gen.add_plan(plans[1])
+        d_inst = q.to_device(inst, R.dev)
+        d0 = q.to_device(gen.initial_state(0.88, batch=batch), R.dev)
+        gen.rollout_inst_torch(d0, d_inst, MC_PREROLL)                      # nominal closed loop: spreads the gait phases
+        tick = lambda st, pu: gen.tick_inst_torch(st, d_inst, pu)
+        desc = (f"Formulation A Monte-Carlo (BASELINE configs[4] per-GPU shape): trot / walk by instance parity, C={Cn}, P={Pn}, per-instance CoM height "
+                f"U(0.50,0.62), step U{{40..100}}, ds=round(0.6 step), F=ceil(C/step)+1 <= 6, Qf 1e7/1e9; {MC_PREROLL} nominal ticks then ONE pushed tick")
+        per_inst = True
+    else:
+        w = workload.make_batch_a(name, batch, stream=rank)
+        Cn, Pn, Fn = w["C"], w["P"], w["F"]
+        g = FA.default_gait(w["kind"], w["phi"], w["disp_A"])
+        _, ce = FA.plan(g)
+        gen = FA.GaitGenerator(FA.default_params(w["kind"], C=Cn, P=Pn, F=Fn), ce, device=R.local_rank, **kw)
+        d0 = q.to_device(w["state"], R.dev); push = w["push"]
+        tick = lambda st, pu: gen.tick_torch(st, pu)
+        desc = (f"Formulation A (MATLAB ISMPC tick with footstep adaptation), {'walk' if w['kind'] == 1 else 'trot'} plan phi=pi/4, C={Cn}, P={Pn}, F={Fn}, "
+                f"step/ds {gen.params.step}/{gen.params.ds}, Qf={gen.params.Qf:g}; nominal state at a random tick + push (SURVEY 8d config 4)")
+        per_inst = False
+    dpush = torch.from_numpy(push.copy()).to(R.dev)
+    d = d0.clone()
+    all_out = torch.empty((world * batch, 80), dtype=torch.uint8, device=("cpu" if R.rehearse else R.dev)) if world > 1 else None
+    last = [None]
+    evs = []
+
+    def step(k):
+        d.copy_(d0)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); o = tick(d, dpush); b.record(); evs.append((a, b))
+        last[0] = o
+        if world > 1:
+            gather_records(o.cpu() if R.rehearse else o, world, out=all_out, counts=[batch] * world)
+
+    walls = timed_regions(R, step, K, W, min_ms)
+    wall = statistics.median(walls)
+    torch.cuda.synchronize()
+    kernel_ms = statistics.median(a.elapsed_time(b) for a, b in evs[W:])
+    o = q.from_device(last[0], FA.OUT_A)
+    res = None
+    if rank == 0:
+        act = ((o["active"] & 0xffff) + (o["active"] >> 16)) / 2.0
+        wmean = float(act.mean())
+        flops = flops_a(Cn, Fn, wmean) * batch
+        peak = PEAK_FP64_TFLOPS if dtype == "f64" else PEAK_FP32_TFLOPS
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        kname = a_kernel_name(Cn, Fn, per_inst, dtype)
+        legkey = leg if dtype == "f64" else f"{leg}_{dtype}"
+        executed, traffic = executed_work(legkey, kname, kernel_ms, batch)
+        value = world * batch / (wall / K)
+        res = {
+            "value": value, "unit": "ticks/s (1 tick = 2 per-axis QPs of C+F variables)", "ms_per_step": 1e3 * wall / K, "dtype": dtype,
+            "qp_solves_per_s": 2.0 * value, "n_gpus": world, "scaling": "weak",
+            "regions": len(walls),
+            "config": {"workload": desc, "horizon": Cn, "batch_per_gpu": batch, "global_batch": world * batch,
+                       "status_nonzero": int((o["status"] != 0).sum()),
+                       "iterations_per_qp_mean": float((o["iters_x"] + o["iters_y"]).mean() / 2),
+                       "iterations_per_qp_max": int(max(o["iters_x"].max(), o["iters_y"].max())),
+                       "working_set_mean": wmean, "working_set_max": int(max((o["active"] & 0xffff).max(), (o["active"] >> 16).max())),
+                       "active_box_fraction": float(((o["active"] & 0xffff) > 1).mean() / 2 + ((o["active"] >> 16) > 1).mean() / 2)},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "kernel": kname, "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                         "algorithmic_bytes_per_launch": 136.0 * batch, "executed": executed,
+                         "note": "algorithmic credit per SURVEY 8d: flops_A = 2[nv w^2 + w^3/3 + 4 nv w + 6 nv], nv = C+F, w = measured mean "
+                                 "working-set size (a dense active-set solve); the structured solver executes less.  kernel_ms = HIP events "
+                                 "around the tick entry point (state copy + clear + the wave kernel; the wave kernel is > 99 % of it)"},
+        }
+    gen.close()
+    return res
+
+
+# ======================================================================================================================
+def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(json.loads(sys.argv[2]))
+        return
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH)
+    ap.add_argument("--horizon", type=int, default=HORIZON)
+    ap.add_argument("--min-region-ms", type=float, default=50.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of oracle work per cpu_baseline measurement")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--only", default=None, help="run ONE leg and print it as the line: headline | config1_b1024 | config3_walk_C150 | "
+                                                  "config4_mc_C200 | shard_b8192 | a_walk_C100 | a_trot_C160 (profiling runs: one kernel shape per process)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="with --only <Formulation A leg>: arithmetic type of the QP solve")
+    args = ap.parse_args()
+
+    R = Ranks(args.gpus)
+    world, rank = R.world, R.rank
+    import quadruped_gait_generation_ismpc_amd as q
+    K, W, M = args.steps, args.warmup, args.min_region_ms
+    a_steps = max(3, min(K, 10))                                        # Formulation A steps take milliseconds
+
+    LEGS = {
+        "headline":         lambda: leg_b(R, q, "headline_b%d" % (args.global_batch // world), args.horizon, args.global_batch, K, W, M, extras=True),
+        "config1_b1024":    lambda: leg_b(R, q, "config1_b1024", args.horizon, 1024, K, W, M, extras=False),
+        "shard_b8192":      lambda: leg_b(R, q, "shard_b8192", args.horizon, 8192, K, W, M, extras=False),
+        "config3_walk_C150": lambda dt="f64": leg_a(R, q, "config3_walk_C150", "walk_C150", A_BATCH, a_steps, 2, M, dt),
+        "config4_mc_C200":  lambda dt="f64": leg_a(R, q, "config4_mc_C200", "mc_C200", A_BATCH, a_steps, 2, M, dt),
+        "a_walk_C100":      lambda dt="f64": leg_a(R, q, "a_walk_C100", "walk_C100", A_BATCH, a_steps, 2, M, dt),
+        "a_trot_C160":      lambda dt="f64": leg_a(R, q, "a_trot_C160", "trot_C160", A_BATCH, a_steps, 2, M, dt),
+    }
+    CPU = {
+        "B": lambda: cpu_baseline("B", "ticks/s", args.cpu_budget, "first instances of the same batch", horizon=args.horizon),
+        "config3_walk_C150": lambda: cpu_baseline("A:walk_C150", "ticks/s", args.cpu_budget, "first instances of the same pushed batch"),
+        "config4_mc_C200": lambda: cpu_baseline("A:mc_C200", "ticks/s", args.cpu_budget,
+                                                f"first instances of the same per-instance draw, {MC_PREROLL} nominal closed-loop ticks + the pushed tick each",
+                                                unit_per_n=MC_PREROLL + 1),
+        "a_walk_C100": lambda: cpu_baseline("A:walk_C100", "ticks/s", args.cpu_budget, "first instances of the same pushed batch"),
+        "a_trot_C160": lambda: cpu_baseline("A:trot_C160", "ticks/s", args.cpu_budget, "first instances of the same pushed batch"),
+    }
+    a_legs = ("config3_walk_C150", "config4_mc_C200", "a_walk_C100", "a_trot_C160")
+    from quadruped_gait_generation_ismpc_amd import formulation_a as FA
+    have_f32 = bool(getattr(FA, "HAVE_F32", False))
+
+    def with_cpu(res, key):
+        if res is not None and world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = CPU[key]()
+        return res
+
+    common = {"n_gpus": world, "steps": K, "warmup": W, "higher_is_better": True, "vs_baseline": None,
+              "data": "synthetic" if not R.rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)"}
+    if args.only:
+        if args.only not in LEGS:
+            raise SystemExit(f"--only: unknown leg {args.only}")
+        res = LEGS[args.only](args.dtype) if args.only in a_legs else LEGS[args.only]()
+        if rank == 0:
+            line = {"metric": "ISMPC QP solves/s (batch, N=100 horizon)" if args.only not in a_legs else "ISMPC ticks/s (Formulation A)"}
+            line.update(res); line.update(common); line.setdefault("scaling", "strong")
+            if args.only in a_legs:
+                line["steps"] = a_steps; line["warmup"] = 2
+            with_cpu(line, args.only if args.only in a_legs else "B")
+            print(json.dumps(line), flush=True)
+        R.close()
+        return
+
+    head = LEGS["headline"]()
+    others = []
+    if not args.no_other_configs:
+        if world == 1:
+            r1 = LEGS["config1_b1024"]()
+            r3 = LEGS["config3_walk_C150"]()
+            r3f = LEGS["config3_walk_C150"]("f32") if have_f32 else None
+        r4 = LEGS["config4_mc_C200"]()
+        r4f = LEGS["config4_mc_C200"]("f32") if have_f32 else None
+    if rank == 0:
+        line = {"metric": "ISMPC QP solves/s (batch, N=100 horizon)"}
+        line.update(head); line.update(common)
+        line["scaling"] = "strong"
+        cpu_b = None
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(N, tick_in, args.cpu_budget)
+            cpu_b = CPU["B"]()
+            line["cpu_baseline"] = cpu_b
+        if not args.no_other_configs:
+            if world == 1:
+                r1.update({"name": "BASELINE configs[1]: 1 024 instances, N=100, fp64, one GPU", "n_gpus": 1, "steps": K, "warmup": W})
+                if cpu_b is not None:
+                    r1["cpu_baseline"] = dict(cpu_b, note="same per-tick workload as the headline (Formulation B, N=100): measured once")
+                others.append(r1)
+                r3.update({"name": "BASELINE configs[3]: walking gait, N=150, batch 16 384, one GPU (fp64 solve)", "steps": a_steps, "warmup": 2})
+                with_cpu(r3, "config3_walk_C150"); others.append(r3)
+                if r3f is not None:
+                    r3f.update({"name": "BASELINE configs[3]: walking gait, N=150, batch 16 384, one GPU (fp32 solve, fp64 state update)", "steps": a_steps, "warmup": 2})
+                    if "cpu_baseline" in r3:
+                        r3f["cpu_baseline"] = r3["cpu_baseline"]
+                    others.append(r3f)
+            r4.update({"name": f"BASELINE configs[4] shape: Monte-Carlo trot/walk, N=200, 16 384 instances per GPU x {world} GPU(s) (fp64 solve)", "steps": a_steps, "warmup": 2})
+            with_cpu(r4, "config4_mc_C200"); others.append(r4)
+            if r4f is not None:
+                r4f.update({"name": f"BASELINE configs[4] shape: Monte-Carlo trot/walk, N=200, 16 384 instances per GPU x {world} GPU(s) (fp32 solve, fp64 state update)", "steps": a_steps, "warmup": 2})
+                if "cpu_baseline" in r4:
+                    r4f["cpu_baseline"] = r4["cpu_baseline"]
+                others.append(r4f)
+            line["other_configs"] = others
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    R.close()
 
 
 if __name__ == "__main__":

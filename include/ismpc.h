@@ -21,7 +21,8 @@
  * re-entrant (like the reference's MPCSolver, which keeps member scratch) but
  * distinct handles are independent.  The compute path is HIP on gfx950; there
  * is NO CPU fallback: without a usable GPU every compute entry point returns
- * ISMPC_E_NO_DEVICE and ismpc_last_error() says why.
+ * ISMPC_E_NO_DEVICE and ismpc_last_error() says why.  Every entry point runs on
+ * the handle's device and restores the caller's current HIP device before it returns.
  */
 #ifndef ISMPC_H
 #define ISMPC_H
@@ -143,6 +144,11 @@ int ismpc_solve_batch_device(ismpc_handle* h, int batch,
 int ismpc_rollout_device(ismpc_handle* h, int batch, ismpc_tick_in* state_dev,
                          int first_frame, int ticks, ismpc_tick_out* traj_dev,
                          void* stream);
+
+/* Optional: size the handle's per-launch scratch for batches up to max_batch now (synchronous).  Without it the
+ * scratch grows inside the asynchronous entry points with stream-ordered allocations (hipMallocAsync on the caller's
+ * stream: no device-wide synchronisation); callers that capture the launches into a hipGraph call this first.  */
+int ismpc_reserve(ismpc_handle* h, int max_batch);
 
 /* Introspection. */
 int         ismpc_abi_version(void);

@@ -107,6 +107,10 @@ int ismpc_a_plan(const ismpc_a_gait* g, double* foot_plan, double* center);
 int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, ismpc_a_handle** out);
 void ismpc_a_destroy(ismpc_a_handle* h);
 
+/* Optional: size the handle's scratch (copy of the previous state, working-set history) for batches up to max_batch now;
+ * otherwise it grows inside the asynchronous entry points with stream-ordered allocations on the caller's stream. */
+int ismpc_a_reserve(ismpc_a_handle* h, int max_batch);
+
 /* State the scripts start from (quad_walk_no_plots.m:52-62). */
 int ismpc_a_initial_state(const ismpc_a_handle* h, double disp_C, ismpc_a_state* st);
 

@@ -273,6 +273,16 @@ void orc_a_set_plan(orc_a_sim* s, const double* fsx, const double* fsy, const do
     memcpy(s->clx + 1, clx, 8 * ncl); memcpy(s->cly + 1, cly, 8 * ncl); s->ncl = ncl;
 }
 
+/* Puts the simulation into the situation a mid-run tick sees, from the compact per-instance record the batched
+ * generators carry (base plan + one plan shift per axis, quad_walk_no_plots.m:535-536; which centreline structure is
+ * live, :86-99 or :540-549): fs_plan = center + off, centreline rebuilt from it.  center as orc_a_create takes it. */
+void orc_a_load_shifted(orc_a_sim* s, const orc_a_state* st, const double* center, double off_x, double off_y, int rebuilt)
+{
+    s->st = *st;
+    for (int i = 1; i <= s->p.n_gait; ++i) { s->fsx[i] = center[i*2] + off_x; s->fsy[i] = center[i*2+1] + off_y; }
+    build_centerline(s, rebuilt ? 0 : 1);
+}
+
 /* One axis of the tick's QP: quad_walk_no_plots.m:153-293 restricted to one coordinate.
  * sol: C+F values (zmp velocities then footsteps). */
 static int solve_axis(orc_a_sim* s, int axis, const double* mapping /* C x (F+1) */, double* sol, int* nwsr_out)

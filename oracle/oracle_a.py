@@ -71,6 +71,7 @@ def _lib():
         lib.orc_a_foot_rows.argtypes = [C.c_void_p]
         lib.orc_a_get_foot_plan.argtypes = [C.c_void_p, C.c_void_p]
         lib.orc_a_foot_trajectories.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.orc_a_load_shifted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int]
         lib._a_ready = True
     return lib
 
@@ -152,6 +153,15 @@ class SimA:
     def state(self, st):
         st = np.ascontiguousarray(st, dtype=STATE_A).reshape(1)
         _lib().orc_a_set_state(self._h, st.ctypes.data_as(C.c_void_p))
+
+    def load_product_state(self, rec):
+        """Mid-run situation from one record of the batched generators' per-instance state (x..cur_y, off_x/off_y =
+        plan shift, fc, j, rebuilt): fs_plan = base plan + shift, centreline rebuilt (quad_walk_no_plots.m:535-549)."""
+        st = np.zeros(1, dtype=STATE_A)
+        for k in ("x", "xd", "xz", "y", "yd", "yz", "cur_x", "cur_y", "fc", "j"):
+            st[k] = rec[k]
+        _lib().orc_a_load_shifted(self._h, st.ctypes.data_as(C.c_void_p), self._center.ctypes.data_as(C.c_void_p),
+                                  float(rec["off_x"]), float(rec["off_y"]), int(rec["rebuilt"]))
 
     def get_plan(self):
         n, m = _lib().orc_a_plan_rows(self._h), _lib().orc_a_cl_len(self._h)

@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libismpc_hip.so")
+LIB_PATH = os.environ.get("ISMPC_LIB") or os.path.join(PKG, "libismpc_hip.so")     # ISMPC_LIB: a tuning sweep's variant build
 
 
 class Params(C.Structure):
@@ -31,7 +31,7 @@ assert TICK_IN.itemsize == 72 and TICK_OUT.itemsize == 80
 EXPORTS = ["ismpc_params_default", "ismpc_create", "ismpc_destroy", "ismpc_solve_batch",
            "ismpc_solve_batch_device", "ismpc_rollout_device", "ismpc_abi_version", "ismpc_last_error",
            "ismpc_get_params", "ismpc_midpoint_rows", "ismpc_get_midpoint", "ismpc_set_timing",
-           "ismpc_last_kernel_ms"]
+           "ismpc_last_kernel_ms", "ismpc_reserve"]
 
 _lib = None
 
@@ -71,6 +71,7 @@ def load():
     lib.ismpc_get_midpoint.argtypes = [vp, vp, ci]; lib.ismpc_get_midpoint.restype = ci
     lib.ismpc_set_timing.argtypes = [vp, ci]; lib.ismpc_set_timing.restype = ci
     lib.ismpc_last_kernel_ms.argtypes = [vp]; lib.ismpc_last_kernel_ms.restype = cd
+    lib.ismpc_reserve.argtypes = [vp, ci]; lib.ismpc_reserve.restype = ci
     _lib = lib
     return lib
 

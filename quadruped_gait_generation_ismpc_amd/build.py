@@ -22,23 +22,37 @@ def _hipcc():
     return exe
 
 
-def _stale(target, sources):
+def _stale(target, sources, flags):
+    """Stale = missing, older than a source, or built with other compiler flags (the flag string is kept next to the .so, so
+    that a tuning sweep's variant can never be mistaken for the default build)."""
     if not os.path.exists(target):
+        return True
+    try:
+        if open(target + ".flags").read() != flags:
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out=None, flags=None):
+    """out: alternative output path (tuning sweeps build their variants there and load them with ISMPC_LIB=<path>; the
+    in-tree default library is never overwritten by a variant).  flags: extra hipcc flags (default: $ISMPC_HIPCC_FLAGS)."""
+    target = out or LIB_HIP
+    flags = os.environ.get("ISMPC_HIPCC_FLAGS", "") if flags is None else flags
+    if out is None and flags.strip():
+        raise RuntimeError("non-default compiler flags need an explicit output path: build(out=..., flags=...) and ISMPC_LIB=<out>")
     hip_src = [os.path.join(CSRC, "ismpc_hip.hip"), os.path.join(CSRC, "ismpc_a_hip.hip"), os.path.join(CSRC, "ismpc_tables.cpp")]
     deps = hip_src + [os.path.join(CSRC, "ismpc_tables.hpp"), os.path.join(ROOT, "include", "ismpc.h"),
                       os.path.join(ROOT, "include", "ismpc_a.h")]
-    out = None if verbose else subprocess.DEVNULL
-    if force or _stale(LIB_HIP, deps):
+    quiet = None if verbose else subprocess.DEVNULL
+    if force or _stale(target, deps, flags):
         subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-I", os.path.join(ROOT, "include")] + os.environ.get("ISMPC_HIPCC_FLAGS", "").split()
-                              + hip_src + ["-o", LIB_HIP], stdout=out)
-    return LIB_HIP
+                               "-I", os.path.join(ROOT, "include")] + flags.split() + hip_src + ["-o", target], stdout=quiet)
+        with open(target + ".flags", "w") as f:
+            f.write(flags)
+    return target
 
 
 if __name__ == "__main__":

@@ -1609,10 +1609,19 @@ __global__ void ismpc_a_clear_out(ismpc_a_out* out, int batch)
     if (i < batch) { out[i].status = 0; out[i].active = 0; out[i].iters_x = 0; out[i].iters_y = 0; }
 }
 
+struct DeviceGuardA {          // entry points leave the caller's current device as they found it
+    int prev = -1, dev; hipError_t err = hipSuccess;
+    explicit DeviceGuardA(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+    }
+    ~DeviceGuardA() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
 thread_local std::string g_err_a = "";
 int fail_a(int code, const std::string& msg) { g_err_a = msg; return code; }
 #define HIP_TRY_A(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
     return fail_a(-2, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+#define ON_DEVICE_A(h_) DeviceGuardA guard_((h_)->device); HIP_TRY_A(guard_.err)
 
 // MATLAB linspace(d1, d2, n)
 void linspace_m(double d1, double d2, int n, std::vector<double>& y)
@@ -1775,7 +1784,8 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     ismpc_a_handle* h = new (std::nothrow) ismpc_a_handle();
     if (!h) return fail_a(-3, "out of host memory");
     h->p = *p; h->device = device;
-    if (hipSetDevice(device) != hipSuccess) { delete h; return fail_a(-2, "hipSetDevice failed"); }
+    DeviceGuardA guard_(device);
+    if (guard_.err != hipSuccess) { delete h; return fail_a(-2, "hipSetDevice failed"); }
     DevA& c = h->c;
     c.C = p->C; c.P = p->P; c.F = p->F; c.step = p->step; c.ds = p->ds; c.n_gait = p->n_gait;
     c.dt = p->dt; c.eta = std::sqrt(p->grav / p->height); c.w = p->w; c.Qf = p->Qf;
@@ -1835,12 +1845,13 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) rc = fail_a(-2, "hipGetDeviceProperties failed");
         else {
             h->slots = prop.multiProcessorCount * (c.sinv_in_lds ? 1 : 4);   // persistent grid: workgroups per CU
+            const int scratch_slots = prop.multiProcessorCount * 4;          // the slab always covers the 4-per-CU grid (the LDS variant may fall back to it)
             h->wave_blocks = prop.multiProcessorCount * 4; h->cus = prop.multiProcessorCount;
             if (hipMalloc((void**)&h->work_counter, sizeof(int)) != hipSuccess) rc = fail_a(-3, "counter allocation failed");
             else h->allocs.push_back(h->work_counter);
             if (const char* e = std::getenv("ISMPC_A_KERNEL")) h->use_wave = std::strcmp(e, "block") != 0;
             void* sc = nullptr;
-            if (hipMalloc(&sc, (size_t)h->slots * c.ldq * c.ldq * sizeof(double)) != hipSuccess) rc = fail_a(-3, "scratch allocation failed");
+            if (hipMalloc(&sc, (size_t)scratch_slots * c.ldq * c.ldq * sizeof(double)) != hipSuccess) rc = fail_a(-3, "scratch allocation failed");
             else { h->allocs.push_back(sc); c.scratch = static_cast<double*>(sc); }
         }
     }
@@ -1856,7 +1867,7 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
 void ismpc_a_destroy(ismpc_a_handle* h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuardA guard_(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->prev) (void)hipFree(h->prev);
     if (h->hist) (void)hipFree(h->hist);
@@ -1878,7 +1889,7 @@ int ismpc_a_add_plan(ismpc_a_handle* h, const double* center)
 {
     if (!h || !center) return fail_a(-1, "null argument");
     if (h->c.nplans >= 4) return fail_a(-1, "at most 4 base plans per handle");
-    HIP_TRY_A(hipSetDevice(h->device));
+    ON_DEVICE_A(h);
     std::vector<double> px(h->p.n_gait), py(h->p.n_gait);
     for (int i = 0; i < h->p.n_gait; ++i) { px[i] = center[i * 2]; py[i] = center[i * 2 + 1]; }
     const int k = h->c.nplans;
@@ -1889,22 +1900,41 @@ int ismpc_a_add_plan(ismpc_a_handle* h, const double* center)
     return k;
 }
 
+int ismpc_a_reserve(ismpc_a_handle* h, int max_batch)
+{
+    if (!h || max_batch < 0) return fail_a(-1, "bad argument");
+    ON_DEVICE_A(h);
+    if (max_batch > h->prev_cap) {
+        if (h->prev) HIP_TRY_A(hipFree(h->prev));
+        h->prev = nullptr; h->prev_cap = 0;
+        HIP_TRY_A(hipMalloc((void**)&h->prev, sizeof(ismpc_a_state) * (size_t)max_batch));
+        h->prev_cap = max_batch;
+    }
+    if (max_batch > h->hist_cap) {
+        if (h->hist) HIP_TRY_A(hipFree(h->hist));
+        h->hist = nullptr; h->hist_cap = 0; h->hist_valid = false;
+        HIP_TRY_A(hipMalloc((void**)&h->hist, sizeof(unsigned long long) * 16 * (size_t)max_batch));
+        h->hist_cap = max_batch;
+    }
+    return 0;
+}
+
 static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev, const double* push_dev,
                        ismpc_a_out* out_dev, void* stream, int history = -1)
 {
     if (!h || batch < 0 || (batch > 0 && !state_dev)) return fail_a(-1, "bad argument");
     if (batch == 0) return 0;
-    HIP_TRY_A(hipSetDevice(h->device));
+    ON_DEVICE_A(h);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // history: -1 = as set by ismpc_a_set_warm_history, 0 = none, 1 = first tick of a rollout (store only), 2 = load + store
     if (history < 0) history = h->hist_ticks ? ((h->hist_valid && h->hist_batch == batch) ? 2 : 1) : 0;
     if (h->c.warm_add <= 0 || h->hist_off) history = 0;
     unsigned long long* hist = nullptr;
     if (history > 0) {
-        if (batch > h->hist_cap) {
-            if (h->hist) (void)hipFree(h->hist);
+        if (batch > h->hist_cap) {                       // stream-ordered growth; ismpc_a_reserve sizes it beforehand
+            if (h->hist) HIP_TRY_A(hipFreeAsync(h->hist, s));
             h->hist = nullptr; h->hist_cap = 0; h->hist_valid = false;
-            HIP_TRY_A(hipMalloc((void**)&h->hist, sizeof(unsigned long long) * 16 * (size_t)batch));
+            HIP_TRY_A(hipMallocAsync((void**)&h->hist, sizeof(unsigned long long) * 16 * (size_t)batch, s));
             h->hist_cap = batch;
         }
         hist = h->hist;
@@ -1913,9 +1943,9 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
     }
     const int hist_load = history == 2 ? 1 : 0;
     if (batch > h->prev_cap) {
-        if (h->prev) (void)hipFree(h->prev);
+        if (h->prev) HIP_TRY_A(hipFreeAsync(h->prev, s));
         h->prev = nullptr; h->prev_cap = 0;
-        HIP_TRY_A(hipMalloc((void**)&h->prev, sizeof(ismpc_a_state) * (size_t)batch));
+        HIP_TRY_A(hipMallocAsync((void**)&h->prev, sizeof(ismpc_a_state) * (size_t)batch, s));
         h->prev_cap = batch;
     }
     HIP_TRY_A(hipMemcpyAsync(h->prev, state_dev, sizeof(ismpc_a_state) * (size_t)batch, hipMemcpyDeviceToDevice, s));
@@ -1996,7 +2026,7 @@ int ismpc_a_feet_init_device(ismpc_a_handle* h, const ismpc_a_gait* g, const dou
                              double* feet_dev, void* stream)
 {
     if (!h || !g || !foot_plan_host || rows < 2 || batch < 0 || (batch > 0 && !feet_dev)) return fail_a(-1, "bad argument");
-    HIP_TRY_A(hipSetDevice(h->device));
+    ON_DEVICE_A(h);
     const int rp = rows + 8;                                       // the walk script writes rows fc+1 .. fc+8
     std::vector<double> base((size_t)rp * 8);
     for (int r = 0; r < rp; ++r) std::memcpy(&base[(size_t)r * 8], foot_plan_host + (size_t)std::min(r, rows - 1) * 8, 64);

@@ -51,6 +51,8 @@ struct DevConst {
     // inequality fallback (0 <= S u <= 1e4 active)
     const double *HSt, *SHSt;
     int* zflag;                       // id of the last launch that deferred an instance to the fallback kernel
+    double* zpool; int* zbusy;        // active-set fallback: slots of zstride doubles (G^-1 cap x cap + per-entry vectors), one lock word per slot
+    int zslots, zcap; size_t zstride;
     // sample-major copies for ismpc_tick_quad: a lane's R samples are one contiguous run (16-byte loads, one base address)
     const double *vq;                 // (npat+1) x NT x 6 : U0,Ua,Ub,SU0,SUa,SUb per sample
     const double *tzg;                // NT x 2 : tz, tg per sample
@@ -534,11 +536,12 @@ template <int R> __device__ __forceinline__ void loadR(const double* p, double (
 }
 
 // ---- vertical QP with active inequality rows (MPCSolver.cpp:158-160: 0 <= S_bar_z u <= 1e4), rare path ----
-// Dual active-set in range-space form over the inequality rows only: the equalities are already inside the
-// reduced inverse P_p = (I - W_p E_p') Hinv, so with p_k = P_p S_k' and g_k = S p_k (rows of the HSt / SHSt tables,
-// pattern folded in with Wt / SW) the Gram matrix of the working set is G[j][k] = g_k[row_j].  Working set
-// <= QZ rows, one lane per entry, its row of G^-1 in that lane's registers.
-constexpr int QZ = 16;
+// Dual active-set (Goldfarb-Idnani step logic) in range-space form over the inequality rows only: the equalities are
+// already inside the reduced inverse P_p = (I - W_p E_p') Hinv, so with p_k = P_p S_k' and g_k = S p_k (rows of the HSt /
+// SHSt tables, pattern folded in with Wt / SW) the Gram matrix of the working set is G[j][k] = g_k[row_j].
+// The working set may grow to every row of the horizon (the reference's solver, utils.cpp:264-383, has no cap either), so
+// G^-1 (q x q) and the per-entry vectors live in a slot of a handle-owned pool in HBM; one wavefront owns a slot while it
+// solves.  Nothing here is on the hot path: the nominal and perturbed gait workloads never activate a row.
 __device__ __forceinline__ double readlane_dyn(double v, int l)
 {
     const int ll = __builtin_amdgcn_readfirstlane(l);
@@ -557,6 +560,12 @@ __device__ __forceinline__ double wave_allmin(double v)
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
     return v;
 }
+__device__ __forceinline__ int wave_allmin_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
 template <int R>
 __device__ __forceinline__ double sample_at(const double (&v)[R], int k)     // v at sample k (k wave-uniform)
 {
@@ -571,6 +580,7 @@ __device__ __forceinline__ void z_fetch(const DevConst& c, int row, int n0, int 
 {
     constexpr int NT = ismpc::Tables::NT;
     loadR<R>(c.HSt + (size_t)row * NT + n0, pc); loadR<R>(c.SHSt + (size_t)row * NT + n0, gc);
+#pragma nounroll
     for (int e = 0; e < ne; ++e) {
         const double ue = c.HSt[(size_t)row * NT + elo + e];
         double wv[R], sv[R];
@@ -581,22 +591,48 @@ __device__ __forceinline__ void z_fetch(const DevConst& c, int row, int n0, int 
 #pragma unroll
     for (int r = 0; r < R; ++r) { const int n = n0 + r; if (n >= elo && n < elo + ne) pc[r] = 0.0; }
 }
-// returns the iteration count; updates u, su in place
-template <int R>
-__device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double (&u)[R], double (&su)[R], int& status)
+// one wavefront's stores to its slot become visible to its other lanes (same CU: a wait for the stores is all it takes)
+#define Z_MEMSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// A slot of the pool: lane 0 takes the first free one starting at `hint`.  Holders always finish (bounded iteration
+// count) and wait for nobody, so spinning here cannot deadlock, whatever is resident.
+__device__ __forceinline__ int z_slot_acquire(const DevConst& c, int lane, int hint)
 {
-    const int N = c.N;
+    int s = 0;
+    if (lane == 0) {
+        s = (int)((unsigned)hint % (unsigned)c.zslots);
+        while (atomicCAS(&c.zbusy[s], 0, 1) != 0) { s = (s + 1 == c.zslots) ? 0 : s + 1; __builtin_amdgcn_s_sleep(8); }
+    }
+    s = __builtin_amdgcn_readfirstlane(s);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return s;
+}
+__device__ __forceinline__ void z_slot_release(const DevConst& c, int lane, int slot)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) atomicExch(&c.zbusy[slot], 0);
+}
+
+// returns the iteration count; updates u, su in place.  Entry j of the working set: row arow[j], bound sign asg[j] (+1 lower,
+// -1 upper), multiplier amu[j]; Ginv = G^-1 over the entries (ld = cap).
+template <int R>
+__device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double (&u)[R], double (&su)[R], int& status, int slot_hint)
+{
+    constexpr int NT = ismpc::Tables::NT;
+    const int N = c.N, cap = c.zcap;
     int elo = 0, ne = 0;
     if (pat < c.npat) { elo = c.e_lo[pat]; ne = c.ne[pat]; }
     const double tol_lo = 1e-11 * fmax(1.0, fabs(c.z_lo)), tol_hi = 1e-11 * fmax(1.0, fabs(c.z_hi));
-    int arow = -1; double asg = 0.0, amu = 0.0;
-    double Srow[QZ];
-#pragma unroll
-    for (int k = 0; k < QZ; ++k) Srow[k] = 0.0;
+    const int slot = z_slot_acquire(c, lane, slot_hint);
+    double* Ginv = c.zpool + (size_t)slot * c.zstride;
+    double* amu = Ginv + (size_t)cap * cap; double* asg = amu + cap; double* rv = asg + cap; double* dv = rv + cap;
+    double* gs = dv + cap;                                   // g of the entering row, by sample (NT)
+    int* arow = reinterpret_cast<int*>(gs + NT);
     bool sact[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) sact[r] = false;
     int q = 0, its = 0;
+    const int max_its = 8 * N + 64;
     for (;;) {
         // ---- most violated free row
         double best = 0.0; int code = 0;
@@ -615,99 +651,109 @@ __device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double
         code = readlane_dyn(code, (int)__builtin_ctzll(m));
         const int row = code >> 1;
         const double sg = (code & 1) ? -1.0 : 1.0;
-        if (q >= QZ) { status |= ISMPC_ST_Z_FAILED; break; }
+        if (q >= cap) { status |= ISMPC_ST_Z_FAILED; break; }             // cannot happen: entries are distinct rows, cap = N
         double pc[R], gc[R];
         z_fetch<R>(c, row, n0, pat, elo, ne, pc, gc);
         const double npn = sample_at<R>(gc, row);
+#pragma unroll
+        for (int r = 0; r < R; ++r) if (n0 + r < NT) gs[n0 + r] = gc[r];
+        Z_MEMSYNC();
         double mu_p = 0.0;
         bool fail = false;
         for (;;) {
-            if (++its > 8 * QZ) { fail = true; break; }
+            if (++its > max_its) { fail = true; break; }
             const double srow = sample_at<R>(su, row);
             const double sviol = sg > 0.0 ? srow - c.z_lo : c.z_hi - srow;
-            // d_j = sg * asg_j * g_row[arow_j]
-            double dj = 0.0;
-            for (int j = 0; j < q; ++j) {
-                const double val = sample_at<R>(gc, readlane_dyn(arow, j));
-                if (lane == j) dj = sg * asg * val;
+            // d_j = sg * asg_j * g_row[arow_j] ;  r = G^-1 d ;  ratio test over the entries
+#pragma nounroll
+            for (int j = lane; j < q; j += 64) dv[j] = sg * asg[j] * gs[arow[j]];
+            Z_MEMSYNC();
+            double drl = 0.0, tcl = INFINITY; int tl = 1 << 30;
+#pragma nounroll
+            for (int j = lane; j < q; j += 64) {
+                double acc = 0.0;
+#pragma nounroll
+                for (int k = 0; k < q; ++k) acc = fma(Ginv[(size_t)k * cap + j], dv[k], acc);       // column j = row j (symmetric)
+                rv[j] = acc; drl = fma(dv[j], acc, drl);
+                if (acc > 0.0) { const double tt = amu[j] / acc; if (tt < tcl) { tcl = tt; tl = j; } }
             }
-            double rj = 0.0;
-#pragma unroll
-            for (int k = 0; k < QZ; ++k) if (k < q) rj += Srow[k] * readlane_dyn(dj, k);
-            if (lane >= q) rj = 0.0;
-            const double gamma = npn - wave_sum((lane < q) ? dj * rj : 0.0);
-            const double tc = (lane < q && rj > 0.0) ? amu / rj : INFINITY;
-            const double t1 = wave_allmin(tc);
+            Z_MEMSYNC();
+            const double gamma = npn - wave_sum(drl);
+            const double t1 = wave_allmin(tcl);
             const double t2 = (gamma > 1e-12 * npn) ? -sviol / gamma : INFINITY;
             const double t = fmin(t1, t2);
             if (!(t < INFINITY)) { fail = true; break; }
             if (t2 < INFINITY) {
-                // z = P (n+ - N r): columns of the active rows, coefficient -r_j asg_j, plus the new one
+                // z = P (n+ - N r): columns of the entries, coefficient -r_j asg_j, plus the new one
                 double zu[R], zs[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) { zu[r] = sg * pc[r]; zs[r] = sg * gc[r]; }
+#pragma nounroll
                 for (int j = 0; j < q; ++j) {
-                    const double cf = -readlane_dyn(rj * asg, j);
+                    const double cf = -rv[j] * asg[j];
                     double pj[R], gj[R];
-                    z_fetch<R>(c, readlane_dyn(arow, j), n0, pat, elo, ne, pj, gj);
+                    z_fetch<R>(c, arow[j], n0, pat, elo, ne, pj, gj);
 #pragma unroll
                     for (int r = 0; r < R; ++r) { zu[r] = fma(cf, pj[r], zu[r]); zs[r] = fma(cf, gj[r], zs[r]); }
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) { u[r] = fma(t, zu[r], u[r]); su[r] = fma(t, zs[r], su[r]); }
             }
-            if (lane < q) amu -= t * rj;
+#pragma nounroll
+            for (int j = lane; j < q; j += 64) amu[j] -= t * rv[j];
             mu_p += t;
             if (t2 < INFINITY && t == t2) {
-                // ---- add: border update of G^-1
+                // ---- the row enters: border update of G^-1
                 const double ig = 1.0 / gamma;
-#pragma unroll
-                for (int k = 0; k < QZ; ++k) {
-                    if (k < q) {
-                        const double rk = readlane_dyn(rj, k);
-                        if (lane < q) Srow[k] = fma(rj * ig, rk, Srow[k]);
-                        if (lane == q) Srow[k] = -rk * ig;
-                    } else if (k == q) {
-                        if (lane < q) Srow[k] = -rj * ig;
-                        if (lane == q) Srow[k] = ig;
-                    }
+    #pragma nounroll
+            for (int j = lane; j < q; j += 64) {
+                    const double rj = rv[j];
+    #pragma nounroll
+                for (int k = 0; k < q; ++k) Ginv[(size_t)k * cap + j] = fma(rv[k] * ig, rj, Ginv[(size_t)k * cap + j]);
+                    Ginv[(size_t)q * cap + j] = -rj * ig; Ginv[(size_t)j * cap + q] = -rj * ig;
                 }
-                if (lane == q) { arow = row; asg = sg; amu = mu_p; }
+                if (lane == 0) { Ginv[(size_t)q * cap + q] = ig; arow[q] = row; asg[q] = sg; amu[q] = mu_p; }
 #pragma unroll
                 for (int r = 0; r < R; ++r) if (n0 + r == row) sact[r] = true;
                 ++q;
+                Z_MEMSYNC();
                 break;
             }
-            // ---- drop entry l (first lane attaining t1): Schur update, last entry moves into slot l
-            const int l = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(tc == t1));
+            // ---- entry l (the first one attaining t1) leaves: Schur update, the last entry moves into its place
+            Z_MEMSYNC();
+            const int l = wave_allmin_i((tcl == t1) ? tl : (1 << 30));
             const int last = q - 1;
-            const int drow = readlane_dyn(arow, l);
-            double coll = 0.0, clast = 0.0;
-#pragma unroll
-            for (int k = 0; k < QZ; ++k) { if (k == l) coll = Srow[k]; if (k == last) clast = Srow[k]; }
-            const double piv = readlane_dyn(coll, l);
-#pragma unroll
-            for (int k = 0; k < QZ; ++k) if (k < q) Srow[k] -= coll * readlane_dyn(Srow[k], l) / piv;   // uses row l before it moves
-            if (l != last) {
-#pragma unroll
-                for (int k = 0; k < QZ; ++k) if (k == last) clast = Srow[k];
-#pragma unroll
-                for (int k = 0; k < QZ; ++k) {
-                    const double vl_ = readlane_dyn(Srow[k], last);
-                    if (lane == l) Srow[k] = vl_;
-                }
-#pragma unroll
-                for (int k = 0; k < QZ; ++k) if (k == l) Srow[k] = (lane == l) ? readlane_dyn(clast, last) : clast;
-                const int ar = readlane_dyn(arow, last); const double as_ = readlane_dyn(asg, last), am = readlane_dyn(amu, last);
-                if (lane == l) { arow = ar; asg = as_; amu = am; }
+            const int drow = arow[l];
+            const double piv = Ginv[(size_t)l * cap + l];
+#pragma nounroll
+            for (int j = lane; j < q; j += 64) rv[j] = Ginv[(size_t)l * cap + j];                   // column l
+            Z_MEMSYNC();
+#pragma nounroll
+            for (int j = lane; j < q; j += 64) {
+                if (j == l) continue;
+                const double cj = rv[j] / piv;
+#pragma nounroll
+                for (int k = 0; k < q; ++k) if (k != l) Ginv[(size_t)k * cap + j] -= rv[k] * cj;
             }
-            if (lane == last) { arow = -1; asg = 0.0; amu = 0.0; }
+            Z_MEMSYNC();
+            if (l != last) {
+    #pragma nounroll
+            for (int j = lane; j < q; j += 64) {
+                    if (j == l) continue;
+                    const double vl_ = Ginv[(size_t)last * cap + j];
+                    Ginv[(size_t)l * cap + j] = vl_; Ginv[(size_t)j * cap + l] = vl_;
+                }
+                Z_MEMSYNC();
+                if (lane == 0) { Ginv[(size_t)l * cap + l] = Ginv[(size_t)last * cap + last]; arow[l] = arow[last]; asg[l] = asg[last]; amu[l] = amu[last]; }
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) if (n0 + r == drow) sact[r] = false;
             --q;
+            Z_MEMSYNC();
         }
         if (fail) { status |= ISMPC_ST_Z_FAILED; break; }
     }
+    z_slot_release(c, lane, slot);
     return its;
 }
 
@@ -789,7 +835,7 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
         const bool anyviol = __builtin_amdgcn_ballot_w64(viol) != 0;
         if (anyviol) {
             status |= ISMPC_ST_Z_INEQ_ACTIVE;
-            if constexpr (FB) zits = z_active_set<R>(c, lane, n0, pat, u, su, status);
+            if constexpr (FB) zits = z_active_set<R>(c, lane, n0, pat, u, su, status, gi);
             else deferred = true;
         }
 #pragma unroll
@@ -987,7 +1033,7 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
         if (zmark && lane == 0) zmark[gi] = deferred ? 1 : 0;
         if (deferred && lane == 0) atomicMax(c.zflag, launch_id);
     }
-    if (rollout_frame >= 0 && lane == 0 && !deferred) {
+    if (rollout_frame >= 0 && lane == 0 && !deferred && !(status & ISMPC_ST_Z_FAILED)) {   // a failed vertical solve is flagged, never fed back
         ismpc_tick_in* st = state_rw + gi;
         st->com_pos[0] = o_x; st->com_pos[1] = o_y; st->com_pos[2] = o_z;
         st->com_vel[0] = o_xd; st->com_vel[1] = o_yd; st->com_vel[2] = o_zd;
@@ -1018,12 +1064,12 @@ void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
 }
 
 // =====================================================================================================================
-// FOUR instances per wavefront, one 16-lane DPP row each (horizons N <= 128).  A horizon of 100 samples
-// fills only 100 of the 128 sample slots of a wavefront and, worse, every scan, reduction and scalar of the tick is paid
-// once per wavefront: with one instance per row the R = ceil(N/16) samples a lane owns are independent work for the
-// FP64 pipe, the scans / reductions are four DPP steps inside a row (no cross-row fold, no readlane), and what used to be
-// wave-uniform is row-uniform.  Same arithmetic as tick_affine_body; instances whose vertical QP has active inequality
-// rows are deferred to the fallback kernel exactly as there.
+// SEVERAL instances per wavefront, one group of LPI lanes each (horizons N <= 128): LPI = 16 (a DPP row, four instances per
+// wavefront) or LPI = 8 (half a row, eight instances).  A horizon of 100 samples fills only 100 of the 128 sample slots of a
+// wavefront and, worse, every scan, reduction and scalar of the tick is paid once per wavefront: with one instance per lane
+// group the R = ceil(N/LPI) samples a lane owns are independent work for the FP64 pipe, the scans / reductions are log2(LPI)
+// DPP steps inside a group (no cross-row fold, no readlane), and what used to be wave-uniform is group-uniform.  Same
+// arithmetic as tick_affine_body; instances whose vertical QP has active inequality rows are deferred exactly as there.
 template <int CTRL, int BANK_MASK>
 __device__ __forceinline__ double dpp64b(double old, double src)
 {
@@ -1039,60 +1085,98 @@ __device__ __forceinline__ double dpp64n(double src)
     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(src), CTRL, 0xf, 0xf, BOUND_ZERO);
     return __hiloint2double(hi, lo);
 }
-// sum over the 16 lanes of the row, in every lane (row_ror:1,2,4,8)
-__device__ __forceinline__ double row_sum(double v)
+// Lane-group primitives.  LPI = 16: the group is a DPP row.  LPI = 8: two groups per row; a shift by 4 is confined to its
+// half row with the bank mask (banks 1 and 3 keep the zero / the old value), shifts by 1 and 2 zero the lanes whose source
+// sits in the neighbouring group; sums are xor butterflies (quad_perm, quad_perm, row_half_mirror).
+template <int LPI> struct Grp;
+template <> struct Grp<16> {
+    static constexpr int STEPS = 4;
+    __device__ static __forceinline__ double sum(double v)             // sum over the group, in every lane (row_ror:1,2,4,8)
+    {
+        v += dpp64n<0x121, false>(v); v += dpp64n<0x122, false>(v); v += dpp64n<0x124, false>(v); v += dpp64n<0x128, false>(v);
+        return v;
+    }
+    __device__ static __forceinline__ int sum_i(int v)
+    {
+        v += __builtin_amdgcn_mov_dpp(v, 0x121, 0xf, 0xf, false); v += __builtin_amdgcn_mov_dpp(v, 0x122, 0xf, 0xf, false);
+        v += __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, false); v += __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false);
+        return v;
+    }
+    // v from lane + 2^K of the group, 0 past its end
+    template <int K> __device__ static __forceinline__ double shl0(double v, int) { return dpp64n<0x100 + (1 << K), true>(v); }
+    // lane 0 of the group, in every lane: quad_perm [0,0,0,0], then row_shr:4 into bank 1, row_shr:8 into banks 2,3
+    __device__ static __forceinline__ double bcast0(double v)
+    {
+        v = dpp64b<0x000, 0xf>(v, v); v = dpp64b<0x114, 0x2>(v, v); v = dpp64b<0x118, 0xc>(v, v);
+        return v;
+    }
+    // v from the next lane of the group; the last lane gets `fill`
+    __device__ static __forceinline__ double next_or(double fill, double v, int) { return dpp64<0x101, 0xf, false>(fill, v); }
+};
+template <> struct Grp<8> {
+    static constexpr int STEPS = 3;
+    __device__ static __forceinline__ double sum(double v)
+    {
+        v += dpp64n<0x0B1, false>(v);                                  // quad_perm [1,0,3,2]
+        v += dpp64n<0x04E, false>(v);                                  // quad_perm [2,3,0,1]
+        v += dpp64n<0x141, false>(v);                                  // row_half_mirror: lane l <-> 7 - l of its half row
+        return v;
+    }
+    __device__ static __forceinline__ int sum_i(int v)
+    {
+        v += __builtin_amdgcn_mov_dpp(v, 0x0B1, 0xf, 0xf, false); v += __builtin_amdgcn_mov_dpp(v, 0x04E, 0xf, 0xf, false);
+        v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false);
+        return v;
+    }
+    template <int K> __device__ static __forceinline__ double shl0(double v, int li)
+    {
+        if constexpr (K == 2) return dpp64b<0x104, 0x5>(0.0, v);      // banks 0 and 2 read lanes + 4; banks 1 and 3 stay 0
+        else { const double t = dpp64n<0x100 + (1 << K), true>(v); return (li + (1 << K) < 8) ? t : 0.0; }
+    }
+    __device__ static __forceinline__ double bcast0(double v)
+    {
+        v = dpp64b<0x000, 0xf>(v, v); v = dpp64b<0x114, 0xa>(v, v);    // quad_perm [0,0,0,0]; banks 1,3 <- banks 0,2
+        return v;
+    }
+    __device__ static __forceinline__ double next_or(double fill, double v, int li)
+    {
+        const double t = dpp64<0x101, 0xf, false>(fill, v);
+        return (li == 7) ? fill : t;
+    }
+};
+// y <- T y for T = I + Tm taken from lane + 2^K of the group (Tm = 0 past the end of the group)
+template <int LPI, int K>
+__device__ __forceinline__ void grp_scan_step(M2& y, int li)
 {
-    v += dpp64n<0x121, false>(v);
-    v += dpp64n<0x122, false>(v);
-    v += dpp64n<0x124, false>(v);
-    v += dpp64n<0x128, false>(v);
-    return v;
-}
-__device__ __forceinline__ int row_sum_i(int v)
-{
-    v += __builtin_amdgcn_mov_dpp(v, 0x121, 0xf, 0xf, false);
-    v += __builtin_amdgcn_mov_dpp(v, 0x122, 0xf, 0xf, false);
-    v += __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, false);
-    v += __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false);
-    return v;
-}
-// y <- T y for T = I + Tm taken from lane + CTRL of the row (Tm = 0 past the end of the row)
-template <int CTRL>
-__device__ __forceinline__ void row_scan_step(M2& y)
-{
-    const double ta = dpp64n<CTRL, true>(y.a - 1.0), tb = dpp64n<CTRL, true>(y.b), tc = dpp64n<CTRL, true>(y.c), td = dpp64n<CTRL, true>(y.d - 1.0);
-    M2 r;
-    r.a = fma(ta, y.a, fma(tb, y.c, y.a)); r.b = fma(ta, y.b, fma(tb, y.d, y.b));
-    r.c = fma(tc, y.a, fma(td, y.c, y.c)); r.d = fma(tc, y.b, fma(td, y.d, y.d));
-    y = r;
-}
-// lane 0 of the row, in every lane: quad_perm [0,0,0,0], then row_shr:4 into bank 1, row_shr:8 into banks 2,3
-__device__ __forceinline__ double row_bcast0(double v)
-{
-    v = dpp64b<0x000, 0xf>(v, v);
-    v = dpp64b<0x114, 0x2>(v, v);
-    v = dpp64b<0x118, 0xc>(v, v);
-    return v;
+    if constexpr (K < Grp<LPI>::STEPS) {
+        const double ta = Grp<LPI>::template shl0<K>(y.a - 1.0, li), tb = Grp<LPI>::template shl0<K>(y.b, li);
+        const double tc = Grp<LPI>::template shl0<K>(y.c, li), td = Grp<LPI>::template shl0<K>(y.d - 1.0, li);
+        M2 r;
+        r.a = fma(ta, y.a, fma(tb, y.c, y.a)); r.b = fma(ta, y.b, fma(tb, y.d, y.b));
+        r.c = fma(tc, y.a, fma(td, y.c, y.c)); r.d = fma(tc, y.b, fma(td, y.d, y.d));
+        y = r;
+    }
 }
 
-template <int R>
-__device__ __forceinline__ bool tick_quad_body(const DevConst& c, const int gi_raw, const int batch, const int lane,
-                                               const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
-                                               ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
-                                               int rollout_frame, unsigned char* zmark, int launch_id)
+// What one instance carries from tick to tick (group-uniform: every lane of the group holds the same values) and what a tick
+// produces (valid in lane 0 of the group).
+struct QState { double x, y, z, xd, yd, zd; Walk w; };
+struct QOut { double x, y, z, xd, yd, zd, uz0, ux0, uy0; int status, itx, ity; };
+
+// One tick of one instance per lane group, registers in, registers out.  `s.w` is the WalkState the tick runs with (caller
+// bookkeeping already applied).  Returns true in every lane of a group whose instance has active vertical inequality rows
+// (deferred to the active-set fallback; its QOut is then provisional).
+template <int R, int LPI>
+__device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lane, const QState& s, QOut& o, double* __restrict__ u_traj_inst)
 {
     constexpr int NT = ismpc::Tables::NT;
     const int N = c.N;
-    const int li = lane & 15;                         // lane inside the row = inside the instance
-    const bool valid = gi_raw < batch;
-    const int gi = valid ? gi_raw : batch - 1;        // tail rows recompute the last instance and store nothing
+    const int li = lane & (LPI - 1);                  // lane inside the group = inside the instance
     const double dt = c.dt;
-    const ismpc_tick_in* rec = ((rollout_frame >= 0) ? state_rw : in_ro) + gi;
-    const Walk w = load_walk(c, rec, rollout_frame);
-    const double x0 = rec->com_pos[0], y0 = rec->com_pos[1], z0 = rec->com_pos[2];
-    const double xd0 = rec->com_vel[0], yd0 = rec->com_vel[1], zd0 = rec->com_vel[2];
+    const Walk& w = s.w;
+    const double x0 = s.x, y0 = s.y, z0 = s.z, xd0 = s.xd, yd0 = s.yd, zd0 = s.zd;
     int idx;
-    const int gate_status = gate_tick(c, w, idx);     // row-uniform; a gated row runs the arithmetic on idx = 0 and drops it
+    const int gate_status = gate_tick(c, w, idx);     // group-uniform; a gated group runs the arithmetic on idx = 0 and drops it
     int status = gate_status;
     const bool run = gate_status == 0;
     if (!run) idx = 0;
@@ -1114,8 +1198,9 @@ __device__ __forceinline__ bool tick_quad_body(const DevConst& c, const int gi_r
         int elo = 0, ne = 0;
         if (pat < c.npat) { elo = c.e_lo[pat]; ne = c.ne[pat]; }
         const int pp = pat < c.npat ? pat : 0;
-        const int nemax = max(max(__builtin_amdgcn_readlane(ne, 0), __builtin_amdgcn_readlane(ne, 16)),
-                              max(__builtin_amdgcn_readlane(ne, 32), __builtin_amdgcn_readlane(ne, 48)));
+        int nemax = 0;
+#pragma unroll
+        for (int g = 0; g < 64; g += LPI) nemax = max(nemax, __builtin_amdgcn_readlane(ne, g));
         const double* dUr = c.dU + (size_t)idx * NT;
         const double* sUr = c.SdU + (size_t)idx * NT;
         double du[R], ds[R];
@@ -1141,7 +1226,7 @@ __device__ __forceinline__ bool tick_quad_body(const DevConst& c, const int gi_r
     const double zlo_t = c.z_lo - 1e-11 * fmax(1.0, fabs(c.z_lo)), zhi_t = c.z_hi + 1e-11 * fmax(1.0, fabs(c.z_hi));
     const bool viol = smin < zlo_t || smax > zhi_t;                                                // MPCSolver.cpp:158-160, beyond rounding
     const unsigned long long vmask = __builtin_amdgcn_ballot_w64(viol);
-    const bool deferred = run && (((vmask >> (lane & 48)) & 0xffffull) != 0ull);
+    const bool deferred = run && (((vmask >> (lane & (64 - LPI))) & ((1ull << LPI) - 1ull)) != 0ull);
     if (deferred) status |= ISMPC_ST_Z_INEQ_ACTIVE;
 
     // ---- lambda_j (MPCSolver.cpp:306) and A_j, B_j (:353-361): A = [1+wQ, dt P; lam dt P, 1+wQ], B = [-wQ, -lam dt P]
@@ -1193,14 +1278,14 @@ __device__ __forceinline__ bool tick_quad_body(const DevConst& c, const int gi_r
             }
         }
     }
-    // ---- inclusive suffix product over the row: Y_l = A(block 15) ... A(block l); C_sc = [1, 1/eta]
+    // ---- inclusive suffix product over the group: Y_l = A(block LPI-1) ... A(block l); C_sc = [1, 1/eta]
     M2 Y = (M2){1.0 + ch1[0], s1[0], s2[0], 1.0 + ch1[0]};
 #pragma unroll
     for (int r = 1; r < R; ++r) Y = mul((M2){1.0 + ch1[r], s1[r], s2[r], 1.0 + ch1[r]}, Y);
-    row_scan_step<0x101>(Y); row_scan_step<0x102>(Y); row_scan_step<0x104>(Y); row_scan_step<0x108>(Y);   // row_shl 1,2,4,8
+    grp_scan_step<LPI, 0>(Y, li); grp_scan_step<LPI, 1>(Y, li); grp_scan_step<LPI, 2>(Y, li); grp_scan_step<LPI, 3>(Y, li);
     const double ie = c.inv_eta;
     const double cva = fma(ie, Y.c, Y.a), cvb = fma(ie, Y.d, Y.b);       // C_sc (suffix product from this lane's first sample)
-    double c0 = dpp64<0x101, 0xf, false>(1.0, cva), c1 = dpp64<0x101, 0xf, false>(ie, cvb);          // the lane needs it one lane up
+    double c0 = Grp<LPI>::next_or(1.0, cva, li), c1 = Grp<LPI>::next_or(ie, cvb, li);                 // the lane needs it one lane up
     // ---- Aeq(n) = C_sc phi_input(:,n) = c_n B_n, walking the lane's samples backwards
     double a[R];
 #pragma unroll
@@ -1219,13 +1304,13 @@ __device__ __forceinline__ bool tick_quad_body(const DevConst& c, const int gi_r
         if (r == 0) { mx0 = mx; my0 = my; }
         q0 = fma(a[r], a[r], q0); s_ax = fma(a[r], mx, s_ax); s_ay = fma(a[r], my, s_ay);
     }
-    q0 = row_sum(q0); s_ax = row_sum(s_ax); s_ay = row_sum(s_ay);
-    // C_sc phi_state sits in lane 0 of the row (cva, cvb there); beq - a'mid (MPCSolver.cpp:381-384), row-uniform
-    const double bpx = row_bcast0((c.tailx[idx] - fma(cva, x0, cvb * xd0)) - s_ax);
-    const double bpy = row_bcast0((c.taily[idx] - fma(cva, y0, cvb * yd0)) - s_ay);
+    q0 = Grp<LPI>::sum(q0); s_ax = Grp<LPI>::sum(s_ax); s_ay = Grp<LPI>::sum(s_ay);
+    // C_sc phi_state sits in lane 0 of the group (cva, cvb there); beq - a'mid (MPCSolver.cpp:381-384), group-uniform
+    const double bpx = Grp<LPI>::bcast0((c.tailx[idx] - fma(cva, x0, cvb * xd0)) - s_ax);
+    const double bpy = Grp<LPI>::bcast0((c.taily[idx] - fma(cva, y0, cvb * yd0)) - s_ay);
     const double sgx = (bpx < 0.0) ? -1.0 : 1.0, sgy = (bpy < 0.0) ? -1.0 : 1.0;
     // min 1/2|v|^2, a'v = bp, |v| <= h  ->  v_n = sg sign(a_n) min(tau |a_n|, h): Newton on the concave piecewise-linear
-    // G(tau) = sum |a_n| min(tau |a_n|, h) from tau = 0; the four rows iterate in lockstep, each with its own state
+    // G(tau) = sum |a_n| min(tau |a_n|, h) from tau = 0; the groups iterate in lockstep, each with its own state
     const double Tq[2] = { fabs(bpx), fabs(bpy) };
     const double iq0 = frcp(q0);
     double tau[2] = { Tq[0] * iq0, Tq[1] * iq0 };
@@ -1249,13 +1334,13 @@ __device__ __forceinline__ bool tick_quad_body(const DevConst& c, const int gi_r
             int cl = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) cl += (tau[ax] * aa[r] >= h) ? 1 : 0;
-            const int cnt = row_sum_i(cl);
+            const int cnt = Grp<LPI>::sum_i(cl);
             if (live[ax] && cnt == prev[ax]) live[ax] = false;                // active set unchanged: exact
             if (__builtin_amdgcn_ballot_w64(live[ax]) == 0ull) continue;
             double ssat = 0.0, qfree = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) { const bool sat = tau[ax] * aa[r] >= h; ssat += sat ? aa[r] : 0.0; qfree += sat ? 0.0 : a[r] * a[r]; }
-            ssat = row_sum(ssat); qfree = row_sum(qfree);
+            ssat = Grp<LPI>::sum(ssat); qfree = Grp<LPI>::sum(qfree);
             if (live[ax]) {
                 ++its[ax];
                 const double rem = Tq[ax] - h * ssat;
@@ -1271,51 +1356,30 @@ __device__ __forceinline__ bool tick_quad_body(const DevConst& c, const int gi_r
         }
     }
 
-    // ---- lane 0 of the row finishes the instance: integration (MPCSolver.cpp:274-278, 406-422), record, feedback
-    if (li == 0 && valid) {
-        double o_x = x0, o_y = y0, o_z = z0, o_xd = xd0, o_yd = yd0, o_zd = zd0;
-        double uz0 = 0.0, ux0 = 0.0, uy0 = 0.0;
-        int itx = 0, ity = 0;
-        if (run) {
-            uz0 = u[0];
-            o_z = z0 + dt * zd0;
-            o_zd = zd0 + c.dt_over_mass * uz0 - dt * c.g;
-            if (isnan(o_z)) { o_z = c.h_des; status |= ISMPC_ST_Z_NAN; }
-            if (isnan(o_zd)) { o_zd = 0.0; status |= ISMPC_ST_Z_NAN; }
-            const double A0a = 1.0 + ch1[0], A0b = s1[0], A0c = s2[0];
-            if (lam0_l > c.gate) {                                            // MPCSolver.cpp:322
-                status |= st3; itx = its[0]; ity = its[1];
-                const double sa0 = (a[0] < 0.0) ? -1.0 : 1.0;
-                ux0 = mx0 + sgx * sa0 * ((aa[0] > 0.0) ? fmin(tau[0] * aa[0], h) : 0.0);
-                uy0 = my0 + sgy * sa0 * ((aa[0] > 0.0) ? fmin(tau[1] * aa[0], h) : 0.0);
-            } else status |= ISMPC_ST_FLIGHT;
-            o_x  = (A0a * x0 + A0b * xd0) + (1.0 - A0a) * ux0;
-            o_xd = (A0c * x0 + A0a * xd0) - A0c * ux0;
-            o_y  = (A0a * y0 + A0b * yd0) + (1.0 - A0a) * uy0;
-            o_yd = (A0c * y0 + A0a * yd0) - A0c * uy0;
-        }
-        if (out) {
-            double2* o2 = reinterpret_cast<double2*>(out + gi);
-            const long long packed = (long long)(unsigned)status | ((long long)(unsigned)((itx & 255) | ((ity & 255) << 8)) << 32);
-            o2[0] = make_double2(o_x, o_y); o2[1] = make_double2(o_z, o_xd); o2[2] = make_double2(o_yd, o_zd);
-            o2[3] = make_double2(uz0, ux0); o2[4] = make_double2(uy0, __longlong_as_double(packed));
-        }
-        if (zmark) zmark[gi] = deferred ? 1 : 0;
-        if (deferred) atomicMax(c.zflag, launch_id);
-        if (rollout_frame >= 0 && !deferred) {                               // Controller.cpp:346-348, :503-504
-            ismpc_tick_in* st = state_rw + gi;
-            st->com_pos[0] = o_x; st->com_pos[1] = o_y; st->com_pos[2] = o_z;
-            st->com_vel[0] = o_xd; st->com_vel[1] = o_yd; st->com_vel[2] = o_zd;
-            st->simulation_time = w.sim;
-            const int ctl = w.ctl + 1;
-            st->control_iter = ctl;
-            st->mpc_iter = (int)floor(ctl * c.cdt / c.dt);     // as written at Controller.cpp:504 (see tick_affine_body)
-            st->footstep_counter = w.fc;
-        }
+    // ---- lane 0 of the group finishes the instance: integration (MPCSolver.cpp:274-278, 406-422)
+    o.x = x0; o.y = y0; o.z = z0; o.xd = xd0; o.yd = yd0; o.zd = zd0;
+    o.uz0 = 0.0; o.ux0 = 0.0; o.uy0 = 0.0; o.itx = 0; o.ity = 0;
+    if (li == 0 && run) {
+        o.uz0 = u[0];
+        o.z = z0 + dt * zd0;
+        o.zd = zd0 + c.dt_over_mass * o.uz0 - dt * c.g;
+        if (isnan(o.z)) { o.z = c.h_des; status |= ISMPC_ST_Z_NAN; }
+        if (isnan(o.zd)) { o.zd = 0.0; status |= ISMPC_ST_Z_NAN; }
+        const double A0a = 1.0 + ch1[0], A0b = s1[0], A0c = s2[0];
+        if (lam0_l > c.gate) {                                            // MPCSolver.cpp:322
+            status |= st3; o.itx = its[0]; o.ity = its[1];
+            const double sa0 = (a[0] < 0.0) ? -1.0 : 1.0;
+            o.ux0 = mx0 + sgx * sa0 * ((aa[0] > 0.0) ? fmin(tau[0] * aa[0], h) : 0.0);
+            o.uy0 = my0 + sgy * sa0 * ((aa[0] > 0.0) ? fmin(tau[1] * aa[0], h) : 0.0);
+        } else status |= ISMPC_ST_FLIGHT;
+        o.x  = (A0a * x0 + A0b * xd0) + (1.0 - A0a) * o.ux0;
+        o.xd = (A0c * x0 + A0a * xd0) - A0c * o.ux0;
+        o.y  = (A0a * y0 + A0b * yd0) + (1.0 - A0a) * o.uy0;
+        o.yd = (A0c * y0 + A0a * yd0) - A0c * o.uy0;
     }
-    if (u_traj && valid) {
-        const bool stage3 = run && row_bcast0(lam0_l) > c.gate;
-        double* dst = u_traj + (size_t)gi * 3 * N;
+    o.status = status;
+    if (u_traj_inst) {
+        const bool stage3 = run && Grp<LPI>::bcast0(lam0_l) > c.gate;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int n = n0 + r;
@@ -1326,9 +1390,53 @@ __device__ __forceinline__ bool tick_quad_body(const DevConst& c, const int gi_r
                     vx = c.midx[idx + n] + sgx * sa * ((aa[r] > 0.0) ? fmin(tau[0] * aa[r], h) : 0.0);
                     vy = c.midy[idx + n] + sgy * sa * ((aa[r] > 0.0) ? fmin(tau[1] * aa[r], h) : 0.0);
                 }
-                dst[n] = run ? u[r] : 0.0; dst[N + n] = vx; dst[2 * N + n] = vy;
+                u_traj_inst[n] = run ? u[r] : 0.0; u_traj_inst[N + n] = vx; u_traj_inst[2 * N + n] = vy;
             }
         }
+    }
+    return deferred;
+}
+
+__device__ __forceinline__ void store_record(ismpc_tick_out* __restrict__ rec, const QOut& o)
+{
+    double2* o2 = reinterpret_cast<double2*>(rec);
+    const long long packed = (long long)(unsigned)o.status | ((long long)(unsigned)((o.itx & 255) | ((o.ity & 255) << 8)) << 32);
+    o2[0] = make_double2(o.x, o.y); o2[1] = make_double2(o.z, o.xd); o2[2] = make_double2(o.yd, o.zd);
+    o2[3] = make_double2(o.uz0, o.ux0); o2[4] = make_double2(o.uy0, __longlong_as_double(packed));
+}
+// Controller.cpp:346-348 (feed the output back), :503-504 (advance the counters)
+__device__ __forceinline__ void store_feedback(const DevConst& c, ismpc_tick_in* __restrict__ st, const QOut& o, const Walk& w)
+{
+    st->com_pos[0] = o.x; st->com_pos[1] = o.y; st->com_pos[2] = o.z;
+    st->com_vel[0] = o.xd; st->com_vel[1] = o.yd; st->com_vel[2] = o.zd;
+    st->simulation_time = w.sim;
+    const int ctl = w.ctl + 1;
+    st->control_iter = ctl;
+    st->mpc_iter = (int)floor(ctl * c.cdt / c.dt);     // as written at Controller.cpp:504 (see tick_affine_body)
+    st->footstep_counter = w.fc;
+}
+
+// One launch = one tick: record in, record out (and, in the host-driven closed loop, state fed back in place)
+template <int R, int LPI>
+__device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_raw, const int batch, const int lane,
+                                                const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
+                                                ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
+                                                int rollout_frame, unsigned char* zmark, int launch_id)
+{
+    const bool valid = gi_raw < batch;
+    const int gi = valid ? gi_raw : batch - 1;        // tail groups recompute the last instance and store nothing
+    const ismpc_tick_in* rec = ((rollout_frame >= 0) ? state_rw : in_ro) + gi;
+    QState s;
+    s.w = load_walk(c, rec, rollout_frame);
+    s.x = rec->com_pos[0]; s.y = rec->com_pos[1]; s.z = rec->com_pos[2];
+    s.xd = rec->com_vel[0]; s.yd = rec->com_vel[1]; s.zd = rec->com_vel[2];
+    QOut o;
+    const bool deferred = tick_group_core<R, LPI>(c, lane, s, o, (u_traj && valid) ? u_traj + (size_t)gi * 3 * c.N : nullptr);
+    if ((lane & (LPI - 1)) == 0 && valid) {
+        if (out) store_record(out + gi, o);
+        if (zmark) zmark[gi] = deferred ? 1 : 0;
+        if (deferred) atomicMax(c.zflag, launch_id);
+        if (rollout_frame >= 0 && !deferred) store_feedback(c, state_rw + gi, o, s.w);
     }
     return deferred && valid;
 }
@@ -1336,40 +1444,123 @@ __device__ __forceinline__ bool tick_quad_body(const DevConst& c, const int gi_r
 #ifndef ISMPC_QUAD_WAVES
 #define ISMPC_QUAD_WAVES 4
 #endif
-template <int R>
+template <int R, int LPI>
 __global__ __launch_bounds__(64 * ISMPC_QUAD_WAVES)
 void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                      ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
                      unsigned char* zmark, int launch_id)
 {
+    constexpr int IPW = 64 / LPI;                      // instances per wavefront
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * ISMPC_QUAD_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave * 4 >= batch) return;
-    tick_quad_body<R>(c, wave * 4 + (lane >> 4), batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+    if (wave * IPW >= batch) return;
+    tick_group_body<R, LPI>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
 }
 
-// Latency variant for small batches (every wavefront resident at once): a wavefront that deferred one of its four
-// instances runs the inequality fallback for it right away, with all 64 lanes, so a step is ONE launch.  The price is
-// the fallback's register budget (2 waves per SIMD), which is why large batches keep the two-launch form.
-template <int R, int RW>
-__global__ __launch_bounds__(64 * ISMPC_QUAD_WAVES)
+// Latency variant for small batches (every wavefront resident at once): a wavefront that deferred one of its
+// instances runs the inequality fallback for it right away, with all 64 lanes, so a step is ONE launch.
+template <int R, int LPI, int RW>
+__global__ __launch_bounds__(64 * ISMPC_QUAD_WAVES, 2)      // two wavefronts per SIMD (that is all a batch that takes this kernel has)
 void ismpc_tick_quad_inline(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                             ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
                             unsigned char* zmark, int launch_id)
 {
+    constexpr int IPW = 64 / LPI;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * ISMPC_QUAD_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave * 4 >= batch) return;
-    const bool def = tick_quad_body<R>(c, wave * 4 + (lane >> 4), batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+    if (wave * IPW >= batch) return;
+    const bool def = tick_group_body<R, LPI>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
     unsigned long long m = __builtin_amdgcn_ballot_w64(def);
     if (m == 0ull) return;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    for (int q = 0; q < 4; ++q)
-        if ((m >> (16 * q)) & 1ull)
-            tick_affine_body<RW, true>(c, wave * 4 + q, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+    for (int q = 0; q < IPW; ++q)
+        if ((m >> (LPI * q)) & 1ull)
+            tick_affine_body<RW, true>(c, wave * IPW + q, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
 }
 
-// Second launch of every tick: exits at once unless the first one deferred instances (active inequality rows).
+// Closed loop inside ONE launch (Controller.cpp:297-310 bookkeeping, :346-348 feedback, :503-504 counters): instances are
+// independent, so a wavefront keeps the state of its instances in registers for `ticks` ticks and writes one trajectory
+// record per tick; nothing but the read-only tables is re-read.  Bit-identical to `ticks` launches of the per-tick kernels
+// (same tick_group_core, same fallback body).
+//   FB = false (the rollout itself): an instance whose vertical inequality rows become active at tick t parks its pre-tick
+//     state in `state`, records t in stop_tick and sits out the rest of the launch;
+//   FB = true (second launch, exits at once unless the first one parked something): one wavefront per parked instance
+//     resumes it at its tick, running the active-set fallback (all 64 lanes, through memory) at the ticks that need it.
+// Keeping the fallback out of the first kernel keeps its register budget that of the tick itself.
+template <int R, int LPI, int RW, bool FB>
+__global__ __launch_bounds__(64 * ISMPC_QUAD_WAVES, 2)
+void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* __restrict__ traj, int batch, int first_frame, int ticks,
+                        int* __restrict__ stop_tick, int launch_id)
+{
+    constexpr int IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63, li = lane & (LPI - 1);
+    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (FB) { if (*c.zflag != launch_id) return; }
+    const int nwork = FB ? batch : (batch + IPW - 1) / IPW;          // FB: one instance per wavefront (every group computes it, group 0 stores)
+    for (int work = wave; work < nwork; work += FB ? (int)gridDim.x * ISMPC_QUAD_WAVES : nwork) {
+        const int gi_raw = FB ? work : work * IPW + lane / LPI;
+        const bool valid = FB ? (lane < LPI) : (gi_raw < batch);
+        const int gi = (gi_raw < batch) ? gi_raw : batch - 1;
+        int t0 = 0;
+        if constexpr (FB) { t0 = stop_tick[gi]; if (t0 < 0) continue; }
+        ismpc_tick_in* rec = state + gi;
+        QState s;
+        s.w.sim = rec->simulation_time; s.w.mpc = rec->mpc_iter; s.w.ctl = rec->control_iter; s.w.fc = rec->footstep_counter;
+        s.x = rec->com_pos[0]; s.y = rec->com_pos[1]; s.z = rec->com_pos[2];
+        s.xd = rec->com_vel[0]; s.yd = rec->com_vel[1]; s.zd = rec->com_vel[2];
+        bool alive = true;                                              // FB = false: false once the instance is parked
+        int stopped = -1;
+        for (int t = t0; t < ticks; ++t) {
+            const int frame = first_frame + t;
+            // caller bookkeeping in front of solve(): Controller.cpp:297-304 (enabled) and :310 -- load_walk's rollout branch
+            const Walk before = s.w;
+            if (s.w.fc >= 0 && s.w.fc < c.rows && s.w.sim >= c.ftsp_t[s.w.fc] - 1) { s.w.ctl = 0; s.w.mpc = 0; s.w.fc = s.w.fc + 1; }
+            s.w.sim = (double)frame;
+            QOut o;
+            const bool def = tick_group_core<R, LPI>(c, lane, s, o, nullptr);
+            const bool park = def && alive;
+            if (li == 0 && valid && alive && !def && traj) store_record(traj + (size_t)t * batch + gi, o);
+            // a deferred instance: its pre-tick state goes to memory (FB = false: to stay there; FB = true: for the fallback body)
+            if (park && valid && li == 0) {
+                rec->com_pos[0] = s.x; rec->com_pos[1] = s.y; rec->com_pos[2] = s.z;
+                rec->com_vel[0] = s.xd; rec->com_vel[1] = s.yd; rec->com_vel[2] = s.zd;
+                rec->simulation_time = before.sim; rec->mpc_iter = before.mpc; rec->control_iter = before.ctl; rec->footstep_counter = before.fc;
+            }
+            if constexpr (!FB) {
+                if (park) { alive = false; stopped = t; }
+            }
+            // feedback (Controller.cpp:346-348) and counters (:503-504), in registers; lane 0 of the group holds the result
+            s.x = Grp<LPI>::bcast0(o.x); s.y = Grp<LPI>::bcast0(o.y); s.z = Grp<LPI>::bcast0(o.z);
+            s.xd = Grp<LPI>::bcast0(o.xd); s.yd = Grp<LPI>::bcast0(o.yd); s.zd = Grp<LPI>::bcast0(o.zd);
+            s.w.ctl = s.w.ctl + 1;
+            s.w.mpc = (int)floor(s.w.ctl * c.cdt / c.dt);
+            if constexpr (FB) {
+                if (__builtin_amdgcn_ballot_w64(def && valid) != 0ull) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    tick_affine_body<RW, true>(c, gi, lane, nullptr, state, traj ? traj + (size_t)t * batch : nullptr, nullptr, frame, nullptr, 0);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    const volatile ismpc_tick_in* vr = rec;
+                    s.x = vr->com_pos[0]; s.y = vr->com_pos[1]; s.z = vr->com_pos[2];
+                    s.xd = vr->com_vel[0]; s.yd = vr->com_vel[1]; s.zd = vr->com_vel[2];
+                    s.w.sim = vr->simulation_time; s.w.mpc = vr->mpc_iter; s.w.ctl = vr->control_iter; s.w.fc = vr->footstep_counter;
+                }
+            }
+        }
+        if (li == 0 && valid) {
+            if (alive) {
+                rec->com_pos[0] = s.x; rec->com_pos[1] = s.y; rec->com_pos[2] = s.z;
+                rec->com_vel[0] = s.xd; rec->com_vel[1] = s.yd; rec->com_vel[2] = s.zd;
+                rec->simulation_time = s.w.sim; rec->mpc_iter = s.w.mpc; rec->control_iter = s.w.ctl; rec->footstep_counter = s.w.fc;
+            }
+            if constexpr (!FB) {
+                stop_tick[gi] = stopped;
+                if (stopped >= 0) atomicMax(c.zflag, launch_id);
+            }
+        }
+    }
+}
+
+// Second launch of every tick of a large batch: exits at once unless the first one deferred instances (active inequality rows).
 template <int R>
 __global__ __launch_bounds__(256)
 void ismpc_tick_affine_fallback(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
@@ -1384,10 +1575,21 @@ void ismpc_tick_affine_fallback(const DevConst c, const ismpc_tick_in* __restric
 }
 
 // ------------------------------------------------------------------------
+// Entry points run on the handle's device and leave the caller's current device as they found it (a torch process that
+// drives several GPUs keeps allocating where it was).
+struct DeviceGuard {
+    int prev = -1, dev; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
 thread_local std::string g_err = "";
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
     return fail(ISMPC_E_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+#define ON_DEVICE(h_) DeviceGuard guard_((h_)->device); HIP_TRY(guard_.err)
 
 }  // namespace
 
@@ -1403,9 +1605,12 @@ struct ismpc_handle {
     bool timing = false; bool timed_pending = false; double last_ms = 0.0;
     int force_waves = 0;      // dense path: 4, 8 or 16 wavefronts per workgroup (0 = 16)
     unsigned char* zmark = nullptr; int zmark_cap = 0; int launch_id = 0; bool z_fallback = true;
+    int* zstop = nullptr; int zstop_cap = 0;     // in-kernel rollouts: tick at which an instance was handed to the resume launch (-1: never)
     bool dense_path = false;  // true: per-tick MFMA solve (ismpc_tick_dense); false: affine tables (ismpc_tick_affine)
     int cus = 0;              // compute units of the device (kernel variant selection); 0: never the one-launch variant
-    bool quad_path = true;    // affine tables, four instances per wavefront (ismpc_tick_quad) where it applies; ISMPC_PATH=wave: one per wavefront
+    bool quad_path = true;    // affine tables, several instances per wavefront (ismpc_tick_quad) where it applies; ISMPC_PATH=wave: one per wavefront
+    int lpi = 16;             // lanes per instance of the quad kernels: 16 (four instances per wavefront) or 8 (eight); ISMPC_LPI
+    bool kernel_rollout = true;   // closed loops run inside one launch (ismpc_rollout_quad); ISMPC_ROLLOUT=host: one launch per tick
 };
 
 namespace {
@@ -1422,6 +1627,18 @@ int upload(ismpc_handle* h, const std::vector<T>& v, const T** dst)
     return ISMPC_OK;
 }
 
+// Shape of the lane-group kernels for horizon N: samples per lane R (the smallest instantiated value that covers N) for
+// LPI = 16 / 8 lanes per instance; RW = samples per lane of the one-instance-per-wavefront fallback body.
+int quad_R(int N, int lpi)
+{
+    const int need = (N + lpi - 1) / lpi;
+    if (lpi == 16) return need <= 4 ? 4 : (need <= 7 ? 7 : 8);
+    return need <= 8 ? 8 : (need <= 13 ? 13 : 16);
+}
+#define ISMPC_SHAPES(X) \
+    if (lpi == 16) { if (RQ == 4) X(4, 16, 1); else if (RQ == 7) X(7, 16, 2); else X(8, 16, 2); } \
+    else           { if (RQ == 8) X(8, 8, 1);   else if (RQ == 13) X(13, 8, 2); else X(16, 8, 2); }
+
 int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* state, ismpc_tick_out* out,
            double* u_traj, int rollout_frame, hipStream_t s)
 {
@@ -1431,44 +1648,35 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
         // fast path: wavefront per instance, 4 per workgroup; then the (normally empty) inequality fallback
         const dim3 grid((batch + 3) / 4), block(256);
         if (h->z_fallback && batch > h->zmark_cap) {
-            if (h->zmark) (void)hipFree(h->zmark);
+            // stream-ordered growth (no device-wide synchronisation inside an asynchronous entry point); callers that
+            // capture graphs size it beforehand with ismpc_reserve
+            if (h->zmark) HIP_TRY(hipFreeAsync(h->zmark, s));
             h->zmark = nullptr; h->zmark_cap = 0;
-            HIP_TRY(hipMalloc((void**)&h->zmark, (size_t)batch));
+            HIP_TRY(hipMallocAsync((void**)&h->zmark, (size_t)batch, s));
             h->zmark_cap = batch;
         }
         unsigned char* zm = h->z_fallback ? h->zmark : nullptr;
         const int lid = ++h->launch_id;
         const dim3 fgrid(std::min((batch + 3) / 4, 64));
-        // default for N <= 128: four instances per wavefront (ismpc_tick_quad); ISMPC_PATH=wave keeps one per wavefront
+        // default for N <= 128: several instances per wavefront (ismpc_tick_quad); ISMPC_PATH=wave keeps one per wavefront
         if (h->quad_path && h->c.N <= 128) {
-            const int RQ = (h->c.N + 15) / 16;
-            const int waves = (batch + 3) / 4;
+            const int lpi = h->lpi, RQ = quad_R(h->c.N, lpi);
+            const int waves = (batch * lpi + 63) / 64;
             const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
             // every wavefront resident at once (<= 2 per SIMD) and a fallback to run: one launch that handles deferred instances itself
-            if (zm && h->cus > 0 && waves <= 8 * h->cus && R <= 2) {
-#define ISMPC_QUADI(RR, RW_) hipLaunchKernelGGL((ismpc_tick_quad_inline<RR, RW_>), qgrid, qblock, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid)
-#define ISMPC_QUADI2(RR) do { if (R == 1) ISMPC_QUADI(RR, 1); else ISMPC_QUADI(RR, 2); } while (0)
-                switch (RQ) {
-                    case 1: ISMPC_QUADI2(1); break; case 2: ISMPC_QUADI2(2); break; case 3: ISMPC_QUADI2(3); break; case 4: ISMPC_QUADI2(4); break;
-                    case 5: ISMPC_QUADI2(5); break; case 6: ISMPC_QUADI2(6); break; case 7: ISMPC_QUADI2(7); break; default: ISMPC_QUADI2(8); break;
-                }
-#undef ISMPC_QUADI2
+            if (zm && h->cus > 0 && waves <= 8 * h->cus) {
+#define ISMPC_QUADI(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad_inline<RR, LL, RW_>), qgrid, qblock, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid)
+                ISMPC_SHAPES(ISMPC_QUADI)
 #undef ISMPC_QUADI
                 HIP_TRY(hipGetLastError());
                 return ISMPC_OK;
             }
-#define ISMPC_QUAD(RR) hipLaunchKernelGGL(ismpc_tick_quad<RR>, qgrid, qblock, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid)
-            switch (RQ) {
-                case 1: ISMPC_QUAD(1); break; case 2: ISMPC_QUAD(2); break; case 3: ISMPC_QUAD(3); break; case 4: ISMPC_QUAD(4); break;
-                case 5: ISMPC_QUAD(5); break; case 6: ISMPC_QUAD(6); break; case 7: ISMPC_QUAD(7); break; default: ISMPC_QUAD(8); break;
-            }
+#define ISMPC_QUAD(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad<RR, LL>), qgrid, qblock, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid)
+            ISMPC_SHAPES(ISMPC_QUAD)
 #undef ISMPC_QUAD
             if (zm) {
-                switch (R) {
-                    case 1: hipLaunchKernelGGL(ismpc_tick_affine_fallback<1>, fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); break;
-                    case 2: hipLaunchKernelGGL(ismpc_tick_affine_fallback<2>, fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); break;
-                    default: return fail(ISMPC_E_UNSUPPORTED, "horizon N > 128 on the quad path");
-                }
+                if (R == 1) hipLaunchKernelGGL(ismpc_tick_affine_fallback<1>, fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid);
+                else        hipLaunchKernelGGL(ismpc_tick_affine_fallback<2>, fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid);
             }
             HIP_TRY(hipGetLastError());
             return ISMPC_OK;
@@ -1551,8 +1759,10 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     }
     if (const char* pth = std::getenv("ISMPC_PATH")) { h->dense_path = std::strcmp(pth, "dense") == 0; h->quad_path = std::strcmp(pth, "wave") != 0 && !h->dense_path; }
     if (const char* zf = std::getenv("ISMPC_Z_FALLBACK")) h->z_fallback = std::atoi(zf) != 0;   // 0: flag only, no second launch
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) { delete h; return fail(ISMPC_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
+    if (const char* lp = std::getenv("ISMPC_LPI")) { const int v = std::atoi(lp); if (v == 8 || v == 16) h->lpi = v; }
+    if (const char* ro = std::getenv("ISMPC_ROLLOUT")) h->kernel_rollout = std::strcmp(ro, "host") != 0;
+    DeviceGuard guard_(device);
+    if (guard_.err != hipSuccess) { delete h; return fail(ISMPC_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard_.err)); }
     { hipDeviceProp_t prop; h->cus = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0; }
     if (const char* fu = std::getenv("ISMPC_ONE_LAUNCH")) { if (std::atoi(fu) == 0) h->cus = 0; }    // 0: always two launches (A/B)
     const ismpc::Tables& t = h->t;
@@ -1586,6 +1796,18 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     if (rc == ISMPC_OK) rc = upload(h, t.SHSt, &c.SHSt);
     if (rc == ISMPC_OK) { std::vector<int> zf(1, 0); const int* zp = nullptr; rc = upload(h, zf, &zp); c.zflag = const_cast<int*>(zp); }
     if (rc == ISMPC_OK) {
+        // active-set fallback pool: 256 slots of (cap x cap + 4 cap + NT) doubles + cap ints, cap = N rows (every row may be active)
+        c.zslots = 256; c.zcap = t.p.N;
+        c.zstride = (size_t)c.zcap * c.zcap + 4 * (size_t)c.zcap + ismpc::Tables::NT + ((size_t)c.zcap + 1) / 2 + 8;
+        std::vector<int> busy(c.zslots, 0); const int* bp = nullptr;
+        rc = upload(h, busy, &bp); c.zbusy = const_cast<int*>(bp);
+        if (rc == ISMPC_OK) {
+            void* zp = nullptr;
+            if (hipMalloc(&zp, c.zstride * c.zslots * sizeof(double)) != hipSuccess) rc = fail(ISMPC_E_ALLOC, "fallback pool allocation failed");
+            else { h->dev_allocs.push_back(zp); c.zpool = static_cast<double*>(zp); }
+        }
+    }
+    if (rc == ISMPC_OK) {
         constexpr int NTq = ismpc::Tables::NT;
         const size_t npp = t.vtab.size() / (6 * (size_t)NTq);
         std::vector<double> vq(t.vtab.size()), tzg(2 * (size_t)NTq), mxy(2 * t.midx.size());
@@ -1609,11 +1831,12 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
 void ismpc_destroy(ismpc_handle* h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard_(h->device);
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->st_in) (void)hipFree(h->st_in);
     if (h->st_out) (void)hipFree(h->st_out);
     if (h->zmark) (void)hipFree(h->zmark);
+    if (h->zstop) (void)hipFree(h->zstop);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1624,7 +1847,7 @@ int ismpc_solve_batch_device(ismpc_handle* h, int batch, const ismpc_tick_in* in
                              double* u_traj, void* stream)
 {
     if (!h || batch < 0 || (batch > 0 && (!in_dev || !out_dev))) return fail(ISMPC_E_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
     int rc = launch(h, batch, in_dev, nullptr, out_dev, u_traj, -1, s);
@@ -1637,7 +1860,7 @@ int ismpc_solve_batch(ismpc_handle* h, int batch, const ismpc_tick_in* in_host, 
 {
     if (!h || batch < 0 || (batch > 0 && (!in_host || !out_host))) return fail(ISMPC_E_INVALID, "bad argument");
     if (batch == 0) return ISMPC_OK;
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     if (batch > h->st_cap) {
         if (h->st_in) (void)hipFree(h->st_in);
         if (h->st_out) (void)hipFree(h->st_out);
@@ -1659,14 +1882,54 @@ int ismpc_rollout_device(ismpc_handle* h, int batch, ismpc_tick_in* state_dev, i
                          ismpc_tick_out* traj_dev, void* stream)
 {
     if (!h || batch < 0 || ticks < 0 || first_frame < 0 || (batch > 0 && !state_dev)) return fail(ISMPC_E_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
-    for (int t = 0; t < ticks; ++t) {
-        int rc = launch(h, batch, nullptr, state_dev, traj_dev ? traj_dev + (size_t)t * batch : nullptr, nullptr, first_frame + t, s);
-        if (rc != ISMPC_OK) return rc;
+    if (batch > 0 && ticks > 0 && h->kernel_rollout && !h->dense_path && h->quad_path && h->c.N <= 128 && h->z_fallback) {
+        // the whole closed loop in ONE launch: state in registers, one trajectory record per tick (ismpc_rollout_quad)
+        const int lpi = h->lpi, RQ = quad_R(h->c.N, lpi);
+        const int waves = (batch * lpi + 63) / 64;
+        const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
+        if (batch > h->zstop_cap) {                       // stream-ordered growth, as zmark (ismpc_reserve sizes it beforehand)
+            if (h->zstop) HIP_TRY(hipFreeAsync(h->zstop, s));
+            h->zstop = nullptr; h->zstop_cap = 0;
+            HIP_TRY(hipMallocAsync((void**)&h->zstop, sizeof(int) * (size_t)batch, s));
+            h->zstop_cap = batch;
+        }
+        const int lid = ++h->launch_id;
+        const dim3 rgrid(std::min((batch + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES, 64));
+#define ISMPC_ROLL(RR, LL, RW_) do { \
+        hipLaunchKernelGGL((ismpc_rollout_quad<RR, LL, RW_, false>), qgrid, qblock, 0, s, h->c, state_dev, traj_dev, batch, first_frame, ticks, h->zstop, lid); \
+        hipLaunchKernelGGL((ismpc_rollout_quad<RR, LL, RW_, true>), rgrid, qblock, 0, s, h->c, state_dev, traj_dev, batch, first_frame, ticks, h->zstop, lid); } while (0)
+        ISMPC_SHAPES(ISMPC_ROLL)
+#undef ISMPC_ROLL
+        HIP_TRY(hipGetLastError());
+    } else {
+        for (int t = 0; t < ticks; ++t) {
+            int rc = launch(h, batch, nullptr, state_dev, traj_dev ? traj_dev + (size_t)t * batch : nullptr, nullptr, first_frame + t, s);
+            if (rc != ISMPC_OK) return rc;
+        }
     }
     if (h->timing) { HIP_TRY(hipEventRecord(h->ev1, s)); h->timed_pending = true; }
+    return ISMPC_OK;
+}
+
+int ismpc_reserve(ismpc_handle* h, int max_batch)
+{
+    if (!h || max_batch < 0) return fail(ISMPC_E_INVALID, "bad argument");
+    ON_DEVICE(h);
+    if (h->z_fallback && max_batch > h->zmark_cap) {
+        if (h->zmark) HIP_TRY(hipFree(h->zmark));
+        h->zmark = nullptr; h->zmark_cap = 0;
+        HIP_TRY(hipMalloc((void**)&h->zmark, (size_t)max_batch));
+        h->zmark_cap = max_batch;
+    }
+    if (max_batch > h->zstop_cap) {
+        if (h->zstop) HIP_TRY(hipFree(h->zstop));
+        h->zstop = nullptr; h->zstop_cap = 0;
+        HIP_TRY(hipMalloc((void**)&h->zstop, sizeof(int) * (size_t)max_batch));
+        h->zstop_cap = max_batch;
+    }
     return ISMPC_OK;
 }
 

@@ -37,7 +37,7 @@ EXPORTS_A = ["ismpc_a_params_default", "ismpc_a_gait_default", "ismpc_a_plan", "
              "ismpc_a_initial_state", "ismpc_a_tick_batch_device", "ismpc_a_rollout_device", "ismpc_a_last_error",
              "ismpc_a_feet_rows", "ismpc_a_feet_init_device", "ismpc_a_tick_feet_batch_device",
              "ismpc_a_rollout_feet_device", "ismpc_a_foot_trajectories", "ismpc_a_write_trajectory_txt",
-             "ismpc_a_add_plan", "ismpc_a_tick_batch_inst_device", "ismpc_a_rollout_inst_device", "ismpc_a_set_warm_history"]
+             "ismpc_a_add_plan", "ismpc_a_tick_batch_inst_device", "ismpc_a_rollout_inst_device", "ismpc_a_set_warm_history", "ismpc_a_reserve"]
 FEET_PAD = 8
 
 _bound = False
@@ -67,6 +67,7 @@ def _l():
         lib.ismpc_a_add_plan.argtypes = [vp, vp]; lib.ismpc_a_add_plan.restype = ci
         lib.ismpc_a_tick_batch_inst_device.argtypes = [vp, ci, vp, vp, vp, vp, vp]; lib.ismpc_a_tick_batch_inst_device.restype = ci
         lib.ismpc_a_rollout_inst_device.argtypes = [vp, ci, vp, vp, ci, vp, vp]; lib.ismpc_a_rollout_inst_device.restype = ci
+        lib.ismpc_a_reserve.argtypes = [vp, ci]; lib.ismpc_a_reserve.restype = ci
         _bound = True
     return lib
 

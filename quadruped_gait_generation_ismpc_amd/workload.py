@@ -53,3 +53,40 @@ def make_batch(N, batch, scale=1.0, seed=SEED, first_instance=0):
     out["com_pos"][:, 2] += scale * PERTURB["pos_z"] * pm(5)
     out["com_vel"][:, 2] += scale * PERTURB["vel_z"] * pm(6)
     return out
+
+
+# ---- Formulation A (the MATLAB generators' tick): BASELINE configs[3], [4] -------------------------------------------
+PUSH_A = (0.03, 0.05)          # xd += U(+-0.03), yd += U(+-0.05)
+
+
+def make_batch_a(name, batch, seed=SEED, stream=0, push_scale=1.0):
+    """SURVEY.md 8d config 4 generator: nominal state at a random tick of the committed closed-loop table
+    tests/golden/prerollA_<name>.npz (walk_C100 | walk_C150 | trot_C160) + an impulsive velocity push.
+    `stream` separates ranks (each rank draws its own instances, no communication).
+    Returns dict(kind, phi, disp_A, C, P, F, state [batch] STATE_A records, push [batch, 2])."""
+    from .formulation_a import STATE_A
+    path = os.path.join(GOLDEN, f"prerollA_{name}.npz")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: run tests/golden/make_golden_a.py:make_prerolls (needs the CPU oracle)")
+    z = np.load(path)
+    tab = z["state"].view(STATE_A).reshape(-1)
+    rng = np.random.Generator(np.random.Philox(key=seed + stream))
+    jj = rng.integers(0, len(tab), batch)
+    push = np.stack([rng.uniform(-PUSH_A[0], PUSH_A[0], batch), rng.uniform(-PUSH_A[1], PUSH_A[1], batch)], 1) * push_scale
+    return dict(kind=int(z["gait"]), phi=float(z["phi"]), disp_A=float(z["disp_A"]), C=int(z["C"]), P=int(z["P"]), F=int(z["F"]),
+                state=tab[jj].copy(), push=np.ascontiguousarray(push))
+
+
+def make_inst_mc(batch, seed=SEED, stream=0, C=200):
+    """SURVEY.md 8d config 5 (BASELINE configs[4]) per-instance draw: trot / walk by instance parity, CoM height ~
+    U(0.50, 0.62), step ~ U{40..100}, ds = round(0.6 step), F = ceil(C / step) + 1, Qf = 1e7 (trot) / 1e9 (walk).
+    Returns (INST_A records [batch], push [batch, 2]); plan 0 = trot plan, plan 1 = walk plan (phi = pi/4, disp_A = 0.1)."""
+    from .formulation_a import INST_A
+    rng = np.random.Generator(np.random.Philox(key=seed + stream))
+    inst = np.zeros(batch, dtype=INST_A)
+    step = rng.integers(40, 101, batch)
+    trot = (np.arange(batch) % 2) == 0
+    inst["height"] = rng.uniform(0.50, 0.62, batch); inst["Qf"] = np.where(trot, 1e7, 1e9); inst["step"] = step
+    inst["ds"] = np.round(0.6 * step).astype(np.int32); inst["F"] = -(-C // step) + 1; inst["plan"] = np.where(trot, 0, 1)
+    push = np.stack([rng.uniform(-PUSH_A[0], PUSH_A[0], batch), rng.uniform(-PUSH_A[1], PUSH_A[1], batch)], 1)
+    return inst, np.ascontiguousarray(push)

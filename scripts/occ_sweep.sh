@@ -1,10 +1,11 @@
 #!/bin/bash
-# rebuilds the library with different residency targets for the Formulation A wave kernel and times each
+# residency targets for the Formulation A wave kernel: variants go to gpurun_out/variants/ (ISMPC_LIB), never in-tree
 set -e
-mkdir -p gpurun_out
+mkdir -p gpurun_out/variants; : > gpurun_out/occ_sweep.log
 for occ in 1 2 3 4; do
-  ISMPC_HIPCC_FLAGS="-DISMPC_A_WAVE_MINBLOCKS=$occ" python -c "from quadruped_gait_generation_ismpc_amd import build; build.build(force=True)" 2>/dev/null
-  for w in walk_C100 walk_C150 trot_C160 mc_C200; do
-    echo "occ=$occ $(timeout -k 10 300 python scripts/bench_a.py $w 16384 5)" | tee -a gpurun_out/occ_sweep.log
+  lib=$PWD/gpurun_out/variants/libismpc_occ$occ.so
+  python -c "from quadruped_gait_generation_ismpc_amd import build; build.build(out='$lib', flags='-DISMPC_A_WAVE_MINBLOCKS=$occ')"
+  for leg in a_walk_C100 config3_walk_C150 a_trot_C160 config4_mc_C200; do
+    echo "occ=$occ $leg $(ISMPC_LIB=$lib timeout -k 10 300 python bench.py --only $leg --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('%.3e' % d['value'], d['roofline']['kernel_ms'])")" | tee -a gpurun_out/occ_sweep.log
   done
 done

@@ -1,21 +1,20 @@
 #!/usr/bin/env python3
 """Per-phase shader-clock breakdown of the Formulation A wave kernel (library built with -DISMPC_A_PROF).
-usage: ISMPC_HIPCC_FLAGS=-DISMPC_A_PROF python -c 'from quadruped_gait_generation_ismpc_amd import build; build.build(force=True)'
-       python scripts/prof_a.py walk_C100 4096"""
-import ctypes as C, os, sys, subprocess
-import numpy as np
+usage: python -c "from quadruped_gait_generation_ismpc_amd import build; build.build(out='gpurun_out/variants/libismpc_prof.so', flags='-DISMPC_A_PROF')"
+       ISMPC_LIB=gpurun_out/variants/libismpc_prof.so python scripts/prof_a.py a_walk_C100"""
+import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
+import bench
+import quadruped_gait_generation_ismpc_amd as q
 from quadruped_gait_generation_ismpc_amd import _lib
+leg = sys.argv[1] if len(sys.argv) > 1 else "a_walk_C100"
+name = {"a_walk_C100": "walk_C100", "config3_walk_C150": "walk_C150", "a_trot_C160": "trot_C160", "config4_mc_C200": "mc_C200"}[leg]
 lib = _lib.load()
 prof = (C.c_ulonglong * 32)()
+R = bench.Ranks(1)
 lib.ismpc_a_debug_prof(prof, 1)
-src = open(os.path.join(ROOT, "scripts", "bench_a.py")).read()
-try:
-    exec(compile(src, "bench_a.py", "exec"))
-except SystemExit:
-    pass
+bench.leg_a(R, q, leg, name, 4096, 3, 1, 1.0)
 lib.ismpc_a_debug_prof(prof, 0)
 names = ["search", "new row+neighbours+h", "small system", "(unused)", "comb/sv", "rho+ratio", "primal/dual step", "enter", "warm pass", "cold restarts", "QP setup", "QP solve (all of the above)", "QP verify + output"]
 tot = prof[10] + prof[11] + prof[12]

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Regenerates EXACTLY the files committed under profiles/r02/ (run on the GPU box, then copy gpurun_out/profiles_r02/* there):
+#   <leg>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of `python3 bench.py --only <leg>` (one kernel shape per process)
+#   <leg>_bench_line.json     the JSON line that same profiled run printed (its roofline.kernel_ms must agree with the CSV)
+#   pmc_<key>.json            PMC passes of the same command, separate runs (--pmc only with --kernel-trace), summarised by
+#                             scripts/pmc_summary.py; <key> is what bench.py's executed_work() looks up
+# usage: scripts/profile_r02.sh [leg ...]        default: every leg bench.py reports
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=$R/gpurun_out/profiles_r02; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+LEGS=${@:-headline shard_b8192 config1_b1024 config3_walk_C150 config4_mc_C200}
+for spec in $LEGS; do
+  leg=${spec%%:*}; dt=f64; [[ $spec == *:* ]] && dt=${spec##*:}
+  case $leg in
+    headline)      key=headline_b65536; kern=ismpc_tick_quad; batch=65536; steps=40 ;;
+    shard_b8192)   key=shard_b8192;     kern=ismpc_tick_quad; batch=8192;  steps=40 ;;
+    config1_b1024) key=config1_b1024;   kern=ismpc_tick_quad; batch=1024;  steps=40 ;;
+    *)             key=$leg;            kern=ismpc_a_tick_wave; batch=16384; steps=5 ;;
+  esac
+  [[ $dt != f64 ]] && key=${key}_$dt
+  CMD="python3 $R/bench.py --only $leg --dtype $dt --no-cpu-baseline --steps $steps --warmup 3 --min-region-ms 5"
+  echo "== $key"
+  rm -rf $OUT/tmp_$key; mkdir -p $OUT/tmp_$key
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp_$key/stats -- $CMD > $OUT/${key}_bench_line.json 2> $OUT/tmp_$key/stats.err || { tail -5 $OUT/tmp_$key/stats.err; exit 1; }
+  cp $(find $OUT/tmp_$key/stats -name "*kernel_stats.csv" | head -1) $OUT/${key}_kernel_stats.csv
+  run() { name=$1; shift; timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/tmp_$key/$name -- $CMD > $OUT/tmp_$key/$name.json 2> $OUT/tmp_$key/$name.err || { tail -5 $OUT/tmp_$key/$name.err; exit 1; }; }
+  run valu SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM
+  run busy SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_F64
+  run fetch FETCH_SIZE
+  run write WRITE_SIZE
+  python3 $R/scripts/pmc_summary.py $OUT/tmp_$key $kern $OUT/pmc_$key.json batch=$batch leg=\"$key\" > /dev/null
+  grep -E "valu_insts_per_wave|hbm_bytes_per_launch|wave_cycles_per_wave" $OUT/pmc_$key.json | tr -d '\n'; echo
+  head -3 $OUT/${key}_kernel_stats.csv | cut -c1-160
+  rm -rf $OUT/tmp_$key/*/*/*agent_info.csv
+done

@@ -11,30 +11,51 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _check_roofline(rf, ms_per_step):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "executed"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma", "valu") and rf["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-9
+    assert 0.0 < rf["kernel_ms"] <= ms_per_step * 1.05                                    # the dominant kernel fits in the step
+    assert abs(rf["achieved"] - rf["algorithmic_flops_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e12) <= 1e-9 * rf["achieved"]
+    if rf["executed"] is not None:
+        assert 0.0 < rf["executed"]["valu_issue_frac"] <= 1.0                              # executed work cannot exceed the pipe
+
+
+def _check_cpu(cb):
+    for k in ("value", "unit", "cores", "kind", "sample", "all_cores", "cpu_model", "nproc"):
+        assert k in cb, k
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
+    assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] >= 0.5 * cb["value"]
+
+
 def test_bench_line_contract(built_libs):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--cpu-budget", "2"],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--cpu-budget", "1.5",
+                        "--min-region-ms", "20"], capture_output=True, text=True, timeout=1100, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "other_configs",
+              "value_incl_pcie", "latency_batch1_us"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
-    B = d["config"]["batch_per_gpu"]
-    assert abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]           # value = instances / step time
-    rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in rf, k
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-9
-    assert 0.0 < rf["kernel_ms"] <= d["ms_per_step"] * 1.05                               # the dominant kernel fits in the step
-    assert abs(rf["achieved"] - rf["algorithmic_flops_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e12) <= 1e-9 * rf["achieved"]
-    cb = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in cb, k
-    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
-    assert d["value"] > 1000 * cb["value"]                                                # the GPU path is not a CPU path in disguise
+    assert d["config"]["global_batch"] == 65536 and d["config"]["batch_per_gpu"] == 65536    # the configuration the metric is quoted on
+    assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]         # value = instances / step time
+    assert d["regions"] >= 3 and d["region_ms"]["median"] * d["regions"] >= 15.0            # the timed work is not a 0.3 ms blip
+    assert 0.0 <= d["config"]["active_box_fraction"] <= 1.0
+    assert d["value_incl_pcie"] < d["value"] and 1.0 < d["latency_batch1_us"] < 1e4
+    _check_roofline(d["roofline"], d["ms_per_step"])
+    _check_cpu(d["cpu_baseline"])
+    assert d["value"] > 1000 * d["cpu_baseline"]["all_cores"]["value"]                     # the GPU path is not a CPU path in disguise
+    names = [o["name"] for o in d["other_configs"]]
+    assert any("configs[1]" in n for n in names) and any("configs[3]" in n for n in names) and any("configs[4]" in n for n in names)
+    for o in d["other_configs"]:
+        for k in ("value", "unit", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline"):
+            assert k in o, (o["name"], k)
+        _check_roofline(o["roofline"], o["ms_per_step"])
+        _check_cpu(o["cpu_baseline"])
+        assert o["value"] > 100 * o["cpu_baseline"]["all_cores"]["value"]

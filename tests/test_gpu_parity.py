@@ -32,7 +32,13 @@ def O():
 
 
 _solvers = {}
-PATHS = ("affine", "wave", "dense")     # affine tables: four instances per wavefront where it applies (default) / one per wavefront; per-tick MFMA formulation
+# affine tables with 16 lanes per instance (four instances per wavefront; default) / 8 lanes per instance (eight) / one instance
+# per wavefront; per-tick MFMA formulation
+PATHS = ("affine", "lpi8", "wave", "dense")
+_ENV = {"affine": {"ISMPC_PATH": "affine", "ISMPC_LPI": "16"}, "lpi8": {"ISMPC_PATH": "affine", "ISMPC_LPI": "8"},
+        "wave": {"ISMPC_PATH": "wave"}, "dense": {"ISMPC_PATH": "dense"},
+        "hostloop": {"ISMPC_PATH": "affine", "ISMPC_LPI": "16", "ISMPC_ROLLOUT": "host"},
+        "hostloop8": {"ISMPC_PATH": "affine", "ISMPC_LPI": "8", "ISMPC_ROLLOUT": "host"}}
 
 
 def solver_for(q, N, path="affine", plan=None, **over):
@@ -43,11 +49,17 @@ def solver_for(q, N, path="affine", plan=None, **over):
         if plan == "stairs":
             for i in range(1, ftsp.shape[0]):
                 ftsp[i, 2] = 0.01 * ((i // 3) % 4)
-        os.environ["ISMPC_PATH"] = path
+        saved = {k: os.environ.get(k) for k in ("ISMPC_PATH", "ISMPC_LPI", "ISMPC_ROLLOUT")}
+        for k in saved:
+            os.environ.pop(k, None)
+        os.environ.update(_ENV[path])
         try:
             _solvers[key] = q.MPCSolver(ftsp, params=p)
         finally:
-            os.environ.pop("ISMPC_PATH", None)
+            for k, v in saved.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
     return _solvers[key]
 
 
@@ -69,6 +81,18 @@ def assert_parity(q, out, ref, ok=None, z_fallback=True):
     scale = np.maximum(np.array([490.5, 1.0, 1.0])[None, :], np.abs(ref["u0"][ok]))
     assert (np.abs(out["u0"] - ref["u0"])[ok] <= TOL * scale).all()
     assert (out["status"][ok] == ref["status"][ok]).all()
+
+
+def _on_feasibility_boundary(q, N, rec, band):
+    """Is one of the two horizontal QPs of this instance within `band` (relative) of infeasibility?  Feasible <=>
+    |beq - a'mid| <= h sum|a| (a box around mid and one equality row); evaluated from the decision trajectories of the
+    HIP path run with the ZMP box widened by (1 +- band)."""
+    res = []
+    for scale in (1.0 - band, 1.0 + band):
+        s = solver_for(q, N, "affine", foot_width=0.09 * scale, first_step_halfwidth=1.0 * scale)
+        o = s.solve_batch(np.array([rec], dtype=q.TICK_IN))
+        res.append(int(o["status"][0]) & (q.ST_X_INFEASIBLE | q.ST_Y_INFEASIBLE))
+    return res[0] != res[1]
 
 
 def load_golden(q, name):
@@ -117,13 +141,18 @@ def test_against_oracle_seeded(q, O, N, scale, path):
     ok = (ref["status"] & q.ST_ERROR_MASK) == 0
     # a QP within 1e-9 of the feasibility boundary may be classified either way: exclude from status equality
     assert ((out["status"] != ref["status"]) & ok).sum() == 0
-    assert ((out["status"] & q.ST_ERROR_MASK) != (ref["status"] & q.ST_ERROR_MASK)).sum() <= 1
-    assert_parity(q, out, ref, z_fallback=(path == "affine"))
+    # a horizontal QP within 1e-9 (relative) of the feasibility boundary may be classified either way by qpOASES' own
+    # termination test (homotopy length 2.2e-7, Options.cpp:206); everything outside that band must agree
+    diff = (out["status"] & q.ST_ERROR_MASK) != (ref["status"] & q.ST_ERROR_MASK)
+    for b in np.where(diff)[0]:
+        assert _on_feasibility_boundary(q, N, tin[b], band=1e-9), (b, out["status"][b], ref["status"][b])
+    assert_parity(q, out, ref, z_fallback=(path != "dense"))
 
 
-@pytest.mark.parametrize("N,over,dz", [(100, dict(z_ineq_hi=4.6), 0.0), (100, dict(z_ineq_hi=4.2), 0.0), (50, dict(), 0.12),
-                                        (37, dict(), 0.10), (150, dict(z_ineq_hi=10.5), 0.0)])
-def test_vertical_inequality_rows_active(q, O, N, over, dz):
+@pytest.mark.parametrize("lay", ["affine", "lpi8"])
+@pytest.mark.parametrize("N,over,dz", [(100, dict(z_ineq_hi=4.6), 0.0), (100, dict(z_ineq_hi=4.2), 0.0), (100, dict(z_ineq_hi=3.2), 0.0),
+                                        (50, dict(), 0.12), (37, dict(), 0.10), (150, dict(z_ineq_hi=10.5), 0.0), (100, dict(), 0.25)])
+def test_vertical_inequality_rows_active(q, O, N, over, dz, lay):
     """0 <= S_bar_z u <= z_hi (MPCSolver.cpp:158-160) made active -- by a tight upper bound (rows at the end of the
     horizon) or by a CoM far above h_des (negative first forces hit the lower bound): the second launch
     (ismpc_tick_affine_fallback) solves the inequality-constrained vertical QP; parity with the oracle's full QP."""
@@ -134,14 +163,14 @@ def test_vertical_inequality_rows_active(q, O, N, over, dz):
         tin = workload.make_batch(150, 48, seed=77 + N)
     tin["com_pos"][:, 2] += dz
     tin["com_vel"][:, 2] += 0.2 * np.sign(dz)
-    s = solver_for(q, N, "affine", **over)
+    s = solver_for(q, N, lay, **over)
     orc = O.Oracle(O.default_params(N, **over))
     ref, info = orc.solve(tin)
     out = s.solve_batch(tin)
     act = (ref["status"] & q.ST_Z_INEQ_ACTIVE) != 0
     assert act.sum() >= 8, act.sum()                           # the case does exercise the fallback
-    okz = (out["status"] & q.ST_Z_FAILED) == 0
-    assert okz[act].mean() > 0.7                               # a few may exceed the 16-row working set: flagged, not wrong
+    assert ((out["status"] & q.ST_Z_FAILED) == 0).all()      # the working set may hold every row of the horizon: nothing is left unsolved
+    assert (((out["status"] & q.ST_Z_INEQ_ACTIVE) != 0) == act).all()
     ok = ((ref["status"] | out["status"]) & q.ST_ERROR_MASK) == 0
     assert (out["status"][ok] == ref["status"][ok]).all()
     assert_parity(q, out, ref, ok)
@@ -264,8 +293,9 @@ def test_closed_loop_rollout_on_device(q, N, ticks, path):
     assert fin["simulation_time"][0] == ticks - 1
 
 
-def test_full_size_properties(q):
-    """BASELINE config 2/3 sizes (1 024 and a 8 192 shard of 65 536): properties that need no oracle.
+def test_full_size_properties(q, O):
+    """BASELINE config 2/3 sizes (1 024, the 8 192 shard and the full 65 536): properties that need no oracle, plus the oracle on a
+    random sample of each batch.
     x/y QPs (MPCSolver.cpp:395-396): equality row satisfied, box respected, and the solution has the
     KKT form u = clip(mid - nu * a) with ONE multiplier nu; z QP: u_i = 0 on the equality samples."""
     import torch
@@ -273,7 +303,7 @@ def test_full_size_properties(q):
     N = 100
     s = solver_for(q, N)
     mid = s.midpoint()
-    for batch in (1024, 8192):
+    for batch in (1024, 8192, 65536):
         tin = workload.make_batch(N, batch, seed=11)
         d_in = q.to_device(tin)
         traj = torch.zeros((batch, 3, N), dtype=torch.float64, device="cuda:0")
@@ -301,6 +331,12 @@ def test_full_size_properties(q):
         # flight instances coast: x' = x + dt * xd
         fl = (st & q.ST_FLIGHT) != 0
         assert np.allclose(out["com_pos"][fl][:, :2], tin["com_pos"][fl][:, :2] + 0.01 * tin["com_vel"][fl][:, :2], rtol=0, atol=1e-15)
+        # the equality row of both horizontal QPs holds: a'u = beq with a, beq recomputed by the oracle for a sample, and the
+        # whole record against the oracle (reference qpOASES where oracle/_ref is built) for the same sample
+        pick = np.random.default_rng(batch).choice(batch, 192, replace=False)
+        ref, info = O.Oracle(O.default_params(N)).solve(tin[pick])
+        assert_parity(q, out[pick], ref)
+        assert (out["status"][pick] == ref["status"]).mean() > 0.98
 
 
 @pytest.mark.parametrize("batch", [8192, 65536])
@@ -313,3 +349,39 @@ def test_bitwise_reproducible_across_launch_variants_of_one_path(q, batch):
     o1 = s.solve_batch_torch(d_in).clone(); o2 = s.solve_batch_torch(d_in).clone()
     torch.cuda.synchronize()
     assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("lay,host", [("affine", "hostloop"), ("lpi8", "hostloop8")])
+@pytest.mark.parametrize("N,ticks,over", [(100, 300, dict()), (50, 200, dict()), (100, 200, dict(z_ineq_hi=5.0)), (50, 200, dict(z_ineq_hi=1.3))])
+def test_in_kernel_rollout_is_bitwise_the_per_tick_loop(q, O, N, ticks, over, lay, host):
+    """ismpc_rollout_device keeps the tick loop inside one launch (ismpc_rollout_quad); ISMPC_ROLLOUT=host runs one launch per
+    tick.  Same bookkeeping (Controller.cpp:297-310,503-504), same arithmetic: byte-identical trajectories and final states --
+    also when the vertical inequality rows become active in the middle of the rollout (tight z_ineq_hi: first active around
+    tick 88; the instance is parked by the first launch and resumed, fallback included, by the second) -- and the
+    unperturbed instance against the oracle's closed loop."""
+    import torch
+    B = 37
+    st0 = O.initial_state().view(q.TICK_IN)
+    recs = np.repeat(st0, B)
+    rng = np.random.default_rng(9)
+    recs["com_pos"][1:, :2] += rng.uniform(-0.004, 0.004, (B - 1, 2))
+    recs["com_vel"][1:, :2] += rng.uniform(-0.02, 0.02, (B - 1, 2))
+    a, b = solver_for(q, N, lay, **over), solver_for(q, N, host, **over)
+    sa, sb = q.to_device(recs), q.to_device(recs)
+    ta = a.rollout_torch(sa, 0, ticks); tb = b.rollout_torch(sb, 0, ticks)
+    torch.cuda.synchronize()
+    assert torch.equal(ta, tb) and torch.equal(sa, sb)
+    out = q.from_device(ta, q.TICK_OUT)                      # [ticks, B]
+    ref, _, _, fin = O.Oracle(O.default_params(N, **over)).rollout(st0, 0, ticks)
+    assert np.array_equal(out["status"][:, 0], ref["status"])
+    assert rel_com(out[:, 0], ref).max() <= TOL
+    endst = q.from_device(sa, q.TICK_IN)
+    for k in ("mpc_iter", "control_iter", "footstep_counter", "simulation_time"):
+        assert endst[k][0] == fin[k][0], k                  # counters bit exact
+    if over:
+        assert ((out["status"] & q.ST_Z_INEQ_ACTIVE) != 0).any(axis=0).all()      # every instance went through the resume launch
+        assert ((out["status"] & q.ST_Z_FAILED) == 0).all()
+    # without a trajectory buffer: same final state
+    sc = q.to_device(recs)
+    a.rollout_torch(sc, 0, ticks, want_traj=False); torch.cuda.synchronize()
+    assert torch.equal(sc, sa)
