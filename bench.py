@@ -285,12 +285,24 @@ def flops_a(C, F, w):
     return 2.0 * (nv * w * w + w ** 3 / 3.0 + 4.0 * nv * w + 6.0 * nv)
 
 
+def _lpi():
+    return 8 if os.environ.get("ISMPC_LPI") == "8" else 16
+
+
+def _quad_r(N, lpi):
+    """csrc/ismpc_hip.hip quad_R(): samples per lane of the lane-group kernels (smallest instantiated value that covers N)."""
+    need = (N + lpi - 1) // lpi
+    if lpi == 16:
+        return 4 if need <= 4 else (7 if need <= 7 else 8)
+    return 8 if need <= 8 else (13 if need <= 13 else 16)
+
+
 def one_launch(N, B, cus):
     """csrc/ismpc_hip.hip launch(): does a step of batch B consist of ONE kernel launch?"""
     path = os.environ.get("ISMPC_PATH")
     if path == "dense" or os.environ.get("ISMPC_Z_FALLBACK") == "0":
         return True
-    return (path != "wave" and N <= 128 and os.environ.get("ISMPC_ONE_LAUNCH") != "0" and (B + 3) // 4 <= 8 * cus)
+    return (path != "wave" and N <= 128 and os.environ.get("ISMPC_ONE_LAUNCH") != "0" and (B * _lpi() + 63) // 64 <= 8 * cus)
 
 
 def kernel_name_b(N, B, cus):
@@ -299,9 +311,10 @@ def kernel_name_b(N, B, cus):
         return "ismpc_tick_dense<%d, 16>" % ((N + 63) // 64)
     if path == "wave" or N > 128:
         return "ismpc_tick_affine<%d>" % ((N + 63) // 64)
+    lpi = _lpi()
     if one_launch(N, B, cus) and os.environ.get("ISMPC_Z_FALLBACK") != "0":
-        return "ismpc_tick_quad_inline<%d, %d>" % ((N + 15) // 16, (N + 63) // 64)
-    return "ismpc_tick_quad<%d>" % ((N + 15) // 16)
+        return "ismpc_tick_quad_inline<%d, %d, %d>" % (_quad_r(N, lpi), lpi, (N + 63) // 64)
+    return "ismpc_tick_quad<%d, %d>" % (_quad_r(N, lpi), lpi)
 
 
 def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
@@ -530,6 +543,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of oracle work per cpu_baseline measurement")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and batch-1 latency measurements (profiling runs: "
+                                                              "every launch of the process then has the leg's own shape)")
     ap.add_argument("--only", default=None, help="run ONE leg and print it as the line: headline | config1_b1024 | config3_walk_C150 | "
                                                   "config4_mc_C200 | shard_b8192 | a_walk_C100 | a_trot_C160 (profiling runs: one kernel shape per process)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="with --only <Formulation A leg>: arithmetic type of the QP solve")
@@ -542,7 +557,7 @@ def main():
     a_steps = max(3, min(K, 10))                                        # Formulation A steps take milliseconds
 
     LEGS = {
-        "headline":         lambda: leg_b(R, q, "headline_b%d" % (args.global_batch // world), args.horizon, args.global_batch, K, W, M, extras=True),
+        "headline":         lambda: leg_b(R, q, "headline_b%d" % (args.global_batch // world), args.horizon, args.global_batch, K, W, M, extras=not args.no_extras),
         "config1_b1024":    lambda: leg_b(R, q, "config1_b1024", args.horizon, 1024, K, W, M, extras=False),
         "shard_b8192":      lambda: leg_b(R, q, "shard_b8192", args.horizon, 8192, K, W, M, extras=False),
         "config3_walk_C150": lambda dt="f64": leg_a(R, q, "config3_walk_C150", "walk_C150", A_BATCH, a_steps, 2, M, dt),

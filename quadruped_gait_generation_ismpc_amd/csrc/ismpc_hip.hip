@@ -33,6 +33,11 @@
 #include <algorithm>
 #include "ismpc_tables.hpp"
 
+// Floating-point contraction is OFF for this file: every fused multiply-add is written as fma().  The same tick arithmetic
+// is inlined into several kernels (per-tick, one-launch, in-kernel rollout, resume) whose results must agree bit for bit,
+// and implicit contraction is a per-context optimiser decision.
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int TI = 16;          // instances per workgroup = MFMA M tile
@@ -57,6 +62,10 @@ struct DevConst {
     const double *vq;                 // (npat+1) x NT x 6 : U0,Ua,Ub,SU0,SUa,SUb per sample
     const double *tzg;                // NT x 2 : tz, tg per sample
     const double *midxy;              // nmid x 2 : midx, midy per sample
+    // the same tables laid out for the lane-group kernels' shape (R samples per lane, LPI lanes per instance), so that one
+    // wave-wide load instruction reads LPI x 16 contiguous bytes per instance (a lane's samples are NOT contiguous here):
+    const double *vqT;                // (npat+1) x R x 3 x LPI double2 : pair k of sample li*R + r at [((p R + r) 3 + k) LPI + li]
+    const double *tzgT;               // R x LPI double2 : (tz, tg) of sample li*R + r at [r LPI + li]
 };
 
 // ---- wavefront (64 lanes) primitives: DPP, no LDS crossbar (ds_bpermute) on the critical path ----
@@ -95,8 +104,8 @@ struct M2 { double a, b, c, d; };   // [a b; c d]
 __device__ __forceinline__ M2 mul(const M2& x, const M2& y)
 {
     M2 r;
-    r.a = x.a*y.a + x.b*y.c; r.b = x.a*y.b + x.b*y.d;
-    r.c = x.c*y.a + x.d*y.c; r.d = x.c*y.b + x.d*y.d;
+    r.a = fma(x.a, y.a, x.b * y.c); r.b = fma(x.a, y.b, x.b * y.d);
+    r.c = fma(x.c, y.a, x.d * y.c); r.d = fma(x.c, y.b, x.d * y.d);
     return r;
 }
 template <int CTRL>
@@ -136,21 +145,21 @@ __device__ __forceinline__ void sinhc_coshc(double w, double& P, double& Q)
 {
     if (__builtin_expect(w <= 0.25, 1)) {
         P = 1.0 / 1307674368000.0;                 // 1/15!
-        P = P * w + 1.0 / 6227020800.0;            // 1/13!
-        P = P * w + 1.0 / 39916800.0;              // 1/11!
-        P = P * w + 1.0 / 362880.0;                // 1/9!
-        P = P * w + 1.0 / 5040.0;                  // 1/7!
-        P = P * w + 1.0 / 120.0;                   // 1/5!
-        P = P * w + 1.0 / 6.0;                     // 1/3!
-        P = P * w + 1.0;
+        P = fma(P, w, 1.0 / 6227020800.0);            // 1/13!
+        P = fma(P, w, 1.0 / 39916800.0);              // 1/11!
+        P = fma(P, w, 1.0 / 362880.0);                // 1/9!
+        P = fma(P, w, 1.0 / 5040.0);                  // 1/7!
+        P = fma(P, w, 1.0 / 120.0);                   // 1/5!
+        P = fma(P, w, 1.0 / 6.0);                     // 1/3!
+        P = fma(P, w, 1.0);
         Q = 1.0 / 20922789888000.0;                // 1/16!
-        Q = Q * w + 1.0 / 87178291200.0;           // 1/14!
-        Q = Q * w + 1.0 / 479001600.0;             // 1/12!
-        Q = Q * w + 1.0 / 3628800.0;               // 1/10!
-        Q = Q * w + 1.0 / 40320.0;                 // 1/8!
-        Q = Q * w + 1.0 / 720.0;                   // 1/6!
-        Q = Q * w + 1.0 / 24.0;                    // 1/4!
-        Q = Q * w + 0.5;
+        Q = fma(Q, w, 1.0 / 87178291200.0);           // 1/14!
+        Q = fma(Q, w, 1.0 / 479001600.0);             // 1/12!
+        Q = fma(Q, w, 1.0 / 3628800.0);               // 1/10!
+        Q = fma(Q, w, 1.0 / 40320.0);                 // 1/8!
+        Q = fma(Q, w, 1.0 / 720.0);                   // 1/6!
+        Q = fma(Q, w, 1.0 / 24.0);                    // 1/4!
+        Q = fma(Q, w, 0.5);
     } else {
         const double x = sqrt(w);
         P = sinh(x) / x;
@@ -586,7 +595,7 @@ __device__ __forceinline__ void z_fetch(const DevConst& c, int row, int n0, int 
         double wv[R], sv[R];
         loadR<R>(c.Wt + ((size_t)pat * c.Fmax + e) * NT + n0, wv); loadR<R>(c.SW + ((size_t)pat * c.Fmax + e) * NT + n0, sv);
 #pragma unroll
-        for (int r = 0; r < R; ++r) { pc[r] -= wv[r] * ue; gc[r] -= sv[r] * ue; }
+        for (int r = 0; r < R; ++r) { pc[r] = fma(-wv[r], ue, pc[r]); gc[r] = fma(-sv[r], ue, gc[r]); }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) { const int n = n0 + r; if (n >= elo && n < elo + ne) pc[r] = 0.0; }
@@ -815,7 +824,7 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
                 double wv[R], sv[R];
                 loadR<R>(c.Wt + ((size_t)pat * c.Fmax + e) * NT + n0, wv); loadR<R>(c.SW + ((size_t)pat * c.Fmax + e) * NT + n0, sv);
 #pragma unroll
-                for (int r = 0; r < R; ++r) { du[r] -= wv[r] * ue; ds[r] -= sv[r] * ue; }
+                for (int r = 0; r < R; ++r) { du[r] = fma(-wv[r], ue, du[r]); ds[r] = fma(-sv[r], ue, ds[r]); }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -841,12 +850,12 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double zpos = su[r] + fma(tz[r], zd0, z0) + tg[r];            // S u + T_bar_z s + T_bar_g_z
-            const double zacc = c.inv_mass * u[r] - c.g;
+            const double zacc = fma(c.inv_mass, u[r], -c.g);
             lam[r] = (c.g + zacc) * frcp(zpos);                                 // MPCSolver.cpp:306
         }
         uz0 = bcast0(u[0]);
-        o_z = z0 + dt * zd0;                                                    // MPCSolver.cpp:274-278
-        o_zd = zd0 + c.dt_over_mass * uz0 - dt * c.g;
+        o_z = fma(dt, zd0, z0);                                                 // MPCSolver.cpp:274-278
+        o_zd = fma(c.dt_over_mass, uz0, zd0) - dt * c.g;
         if (isnan(o_z)) { o_z = c.h_des; status |= ISMPC_ST_Z_NAN; }
         if (isnan(o_zd)) { o_zd = 0.0; status |= ISMPC_ST_Z_NAN; }
 
@@ -926,7 +935,7 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
             // ---- Aeq(n) = C_sc phi_input(:,n) = c_n B_n, walking the lane's samples backwards
 #pragma unroll
             for (int r = R - 1; r >= 0; --r) {
-                a[r] = -(c0 * ch1[r] + c1 * s2[r]);
+                a[r] = -fma(c0, ch1[r], c1 * s2[r]);
                 const double k0 = fma(c0, ch1[r], fma(c1, s2[r], c0)), k1 = fma(c1, ch1[r], fma(c0, s1[r], c1));
                 c0 = k0; c1 = k1;
             }
@@ -969,12 +978,12 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
                     if (cnt == prev) break;                                      // active set unchanged: exact
                     double ssat = 0.0, qfree = 0.0;
 #pragma unroll
-                    for (int r = 0; r < R; ++r) { const bool sat = tau[ax] * aa[r] >= h; ssat += sat ? aa[r] : 0.0; qfree += sat ? 0.0 : a[r] * a[r]; }
+                    for (int r = 0; r < R; ++r) { const bool sat = tau[ax] * aa[r] >= h; ssat += sat ? aa[r] : 0.0; const double a2 = a[r] * a[r]; qfree += sat ? 0.0 : a2; }
                     ssat = wave_sum(ssat); qfree = wave_sum(qfree);
                     ++its[ax];
-                    const double rem = T[ax] - h * ssat;
+                    const double rem = fma(-h, ssat, T[ax]);
                     if (!(qfree > 0.0)) {                                        // everything saturated
-                        if (rem > h * ssat * 1e-12 + 1e-300) status |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
+                        if (rem > fma(h * ssat, 1e-12, 1e-300)) status |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
                         tau[ax] = INFINITY; break;
                     }
                     const double tn = rem * frcp(qfree);
@@ -986,17 +995,17 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
             {   // first decision variables (lane 0 holds sample 0)
                 const double a0 = bcast0(a[0]), aa0 = fabs(a0), sa0 = (a0 < 0.0) ? -1.0 : 1.0;
                 const double m0x = bcast0(mx[0]), m0y = bcast0(my[0]);
-                ux0 = m0x + sgx * sa0 * ((aa0 > 0.0) ? fmin(tau0 * aa0, h) : 0.0);
-                uy0 = m0y + sgy * sa0 * ((aa0 > 0.0) ? fmin(tau1 * aa0, h) : 0.0);
+                ux0 = fma(sgx * sa0, (aa0 > 0.0) ? fmin(tau0 * aa0, h) : 0.0, m0x);
+                uy0 = fma(sgy * sa0, (aa0 > 0.0) ? fmin(tau1 * aa0, h) : 0.0, m0y);
             }
         } else {
             status |= ISMPC_ST_FLIGHT;
         }
         // ---- integration with A(lambda_0), B(lambda_0), MPCSolver.cpp:406-422
-        o_x  = (A0a * x0 + A0b * xd0) + (1.0 - A0a) * ux0;
-        o_xd = (A0c * x0 + A0a * xd0) - A0c * ux0;
-        o_y  = (A0a * y0 + A0b * yd0) + (1.0 - A0a) * uy0;
-        o_yd = (A0c * y0 + A0a * yd0) - A0c * uy0;
+        o_x  = fma(1.0 - A0a, ux0, fma(A0a, x0, A0b * xd0));
+        o_xd = fma(-A0c, ux0, fma(A0c, x0, A0a * xd0));
+        o_y  = fma(1.0 - A0a, uy0, fma(A0a, y0, A0b * yd0));
+        o_yd = fma(-A0c, uy0, fma(A0c, y0, A0a * yd0));
     }
 
     // ---- 80-byte output record: lanes 0..9 store one 8-byte word each
@@ -1021,8 +1030,8 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
                 double vx = 0.0, vy = 0.0;
                 if (stage3) {
                     const double aa = fabs(a[r]), sa = (a[r] < 0.0) ? -1.0 : 1.0;
-                    vx = c.midx[idx + n] + sgx * sa * ((aa > 0.0) ? fmin(tau0 * aa, hbox) : 0.0);
-                    vy = c.midy[idx + n] + sgy * sa * ((aa > 0.0) ? fmin(tau1 * aa, hbox) : 0.0);
+                    vx = fma(sgx * sa, (aa > 0.0) ? fmin(tau0 * aa, hbox) : 0.0, c.midx[idx + n]);
+                    vy = fma(sgy * sa, (aa > 0.0) ? fmin(tau1 * aa, hbox) : 0.0, c.midy[idx + n]);
                 }
                 dst[n] = u[r]; dst[N + n] = vx; dst[2 * N + n] = vy;
             }
@@ -1158,6 +1167,23 @@ __device__ __forceinline__ void grp_scan_step(M2& y, int li)
     }
 }
 
+// -DISMPC_STAMPS (diagnostic build, scripts/stamps_b.py): wall-clock stamps (s_memrealtime, 100 MHz) of every wavefront of the
+// per-tick lane-group kernels at a few points of the tick; written to a buffer nothing else reads.
+#ifdef ISMPC_STAMPS
+__device__ unsigned long long g_stamps[16384 * 8];
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define STAMP(k_) do { if (g_stamp_wave >= 0 && g_stamp_wave < 16384) { const unsigned long long t_ = stamp_now(); if ((threadIdx.x & 63) == 0) g_stamps[g_stamp_wave * 8 + (k_)] = t_; } } while (0)
+#define STAMP_DECL const int g_stamp_wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)
+#else
+#define STAMP(k_) do {} while (0)
+#define STAMP_DECL do {} while (0)
+#endif
+
 // What one instance carries from tick to tick (group-uniform: every lane of the group holds the same values) and what a tick
 // produces (valid in lane 0 of the group).
 struct QState { double x, y, z, xd, yd, zd; Walk w; };
@@ -1166,8 +1192,15 @@ struct QOut { double x, y, z, xd, yd, zd, uz0, ux0, uy0; int status, itx, ity; }
 // One tick of one instance per lane group, registers in, registers out.  `s.w` is the WalkState the tick runs with (caller
 // bookkeeping already applied).  Returns true in every lane of a group whose instance has active vertical inequality rows
 // (deferred to the active-set fallback; its QOut is then provisional).
+// LDS of one wavefront of the lane-group kernels: the midpoint window of each of its instances, staged so that the global
+// loads are coalesced (lane li reads sample k LPI + li) and every lane then picks up its own R consecutive samples.  A lane's
+// block starts at li * MIDM double2; MIDM is odd, which keeps the 16-byte reads of 16 lanes on 16 different bank quads.
+template <int R> constexpr int midm() { return R | 1; }
+template <int R, int LPI> constexpr int wave_lds_double2() { return (64 / LPI) * LPI * midm<R>(); }
+
 template <int R, int LPI>
-__device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lane, const QState& s, QOut& o, double* __restrict__ u_traj_inst)
+__device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lane, const QState& s, QOut& o, double* __restrict__ u_traj_inst,
+                                                double2* __restrict__ lds_wave)
 {
     constexpr int NT = ismpc::Tables::NT;
     const int N = c.N;
@@ -1181,15 +1214,25 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
     const bool run = gate_status == 0;
     if (!run) idx = 0;
     const int n0 = li * R;                            // this lane owns samples n0 .. n0+R-1 (tables are zero past N)
+    STAMP_DECL;
+    STAMP(1);                                         // the record has arrived (gate_tick consumed it)
 
     // ---- vertical stage from the affine tables (MPCSolver.cpp:223-243, is_running :262-263)
     const int pat = (run && w.fc > 1 && w.mpc < c.npat) ? w.mpc : c.npat;
-    const double2* T = reinterpret_cast<const double2*>(c.vq + ((size_t)pat * NT + n0) * 6);     // 3 x 16 bytes per sample
+    const double2* T = reinterpret_cast<const double2*>(c.vqT) + (size_t)pat * (R * 3 * LPI) + li;  // 3 x 16 bytes per sample, lane-contiguous
+    // midpoint window [idx, idx + LPI R) of this instance -> LDS, coalesced (consumed after the scan; MPCSolver.cpp:328-338,388-389)
+    constexpr int MIDM = midm<R>();
+    double2* Lm = lds_wave + (lane / LPI) * (LPI * MIDM);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int j = k * LPI + li;
+        Lm[(j / R) * MIDM + (j % R)] = reinterpret_cast<const double2*>(c.midxy)[min(idx + j, c.nmid - 1)];
+    }
     double u[R], su[R];
     double smin = INFINITY, smax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const double2 t01 = T[3 * r], t23 = T[3 * r + 1], t45 = T[3 * r + 2];
+        const double2 t01 = T[(3 * r) * LPI], t23 = T[(3 * r + 1) * LPI], t45 = T[(3 * r + 2) * LPI];
         u[r] = fma(zd0, t23.x, fma(z0, t01.y, t01.x));
         su[r] = fma(zd0, t45.y, fma(z0, t45.x, t23.y));
         if (n0 + r < N) { smin = fmin(smin, su[r]); smax = fmax(smax, su[r]); }
@@ -1212,7 +1255,7 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
             const double* wr = c.Wt + ((size_t)pp * c.Fmax + (on ? e : 0)) * NT + n0;
             const double* sr = c.SW + ((size_t)pp * c.Fmax + (on ? e : 0)) * NT + n0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { du[r] -= wr[r] * ue; ds[r] -= sr[r] * ue; }
+            for (int r = 0; r < R; ++r) { du[r] = fma(-wr[r], ue, du[r]); ds[r] = fma(-sr[r], ue, ds[r]); }
         }
         smin = INFINITY; smax = -INFINITY;
 #pragma unroll
@@ -1236,9 +1279,9 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
         double wv_[R], le_[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const double2 tq = reinterpret_cast<const double2*>(c.tzg)[n0 + r];
+            const double2 tq = reinterpret_cast<const double2*>(c.tzgT)[r * LPI + li];
             const double zpos = su[r] + fma(tq.x, zd0, z0) + tq.y;                  // S u + T_bar_z s + T_bar_g_z
-            const double zacc = c.inv_mass * u[r] - c.g;
+            const double zacc = fma(c.inv_mass, u[r], -c.g);
             const double lam = (c.g + zacc) * frcp(zpos);
             if (r == 0) lam0_l = lam;
             le_[r] = (lam < c.gate) ? 0.0 : lam;
@@ -1282,6 +1325,7 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
     M2 Y = (M2){1.0 + ch1[0], s1[0], s2[0], 1.0 + ch1[0]};
 #pragma unroll
     for (int r = 1; r < R; ++r) Y = mul((M2){1.0 + ch1[r], s1[r], s2[r], 1.0 + ch1[r]}, Y);
+    STAMP(2);                                         // tables arrived, lambda / A_j / local products done
     grp_scan_step<LPI, 0>(Y, li); grp_scan_step<LPI, 1>(Y, li); grp_scan_step<LPI, 2>(Y, li); grp_scan_step<LPI, 3>(Y, li);
     const double ie = c.inv_eta;
     const double cva = fma(ie, Y.c, Y.a), cvb = fma(ie, Y.d, Y.b);       // C_sc (suffix product from this lane's first sample)
@@ -1290,16 +1334,17 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
     double a[R];
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) {
-        a[r] = -(c0 * ch1[r] + c1 * s2[r]);
+        a[r] = -fma(c0, ch1[r], c1 * s2[r]);
         const double k0 = fma(c0, ch1[r], fma(c1, s2[r], c0)), k1 = fma(c1, ch1[r], fma(c0, s1[r], c1));
         c0 = k0; c1 = k1;
     }
     const double h = (w.fc > 1) ? c.half_run : c.half_first;                                          // MPCSolver.cpp:328-338
     double q0 = 0.0, s_ax = 0.0, s_ay = 0.0, mx0 = 0.0, my0 = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();          // the staged window is complete
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int n = n0 + r;
-        const double2 mq = reinterpret_cast<const double2*>(c.midxy)[min(idx + n, c.nmid - 1)];
+        const double2 mq = Lm[li * MIDM + r];
         const double mx = (n < N) ? mq.x : 0.0, my = (n < N) ? mq.y : 0.0;
         if (r == 0) { mx0 = mx; my0 = my; }
         q0 = fma(a[r], a[r], q0); s_ax = fma(a[r], mx, s_ax); s_ay = fma(a[r], my, s_ay);
@@ -1309,6 +1354,7 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
     const double bpx = Grp<LPI>::bcast0((c.tailx[idx] - fma(cva, x0, cvb * xd0)) - s_ax);
     const double bpy = Grp<LPI>::bcast0((c.taily[idx] - fma(cva, y0, cvb * yd0)) - s_ay);
     const double sgx = (bpx < 0.0) ? -1.0 : 1.0, sgy = (bpy < 0.0) ? -1.0 : 1.0;
+    STAMP(3);                                         // scan, backward walk, midpoints, reductions done
     // min 1/2|v|^2, a'v = bp, |v| <= h  ->  v_n = sg sign(a_n) min(tau |a_n|, h): Newton on the concave piecewise-linear
     // G(tau) = sum |a_n| min(tau |a_n|, h) from tau = 0; the groups iterate in lockstep, each with its own state
     const double Tq[2] = { fabs(bpx), fabs(bpy) };
@@ -1317,9 +1363,6 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
     int its[2] = {1, 1}, prev[2] = {0, 0};
     bool live[2] = {true, true};
     int st3 = 0;
-    double aa[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) aa[r] = fabs(a[r]);
     if (!(q0 > 0.0)) {                                                       // no sample can move the ZMP
 #pragma unroll
         for (int ax = 0; ax < 2; ++ax) {
@@ -1333,19 +1376,19 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
         for (int ax = 0; ax < 2; ++ax) {
             int cl = 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) cl += (tau[ax] * aa[r] >= h) ? 1 : 0;
+            for (int r = 0; r < R; ++r) cl += (tau[ax] * fabs(a[r]) >= h) ? 1 : 0;
             const int cnt = Grp<LPI>::sum_i(cl);
             if (live[ax] && cnt == prev[ax]) live[ax] = false;                // active set unchanged: exact
             if (__builtin_amdgcn_ballot_w64(live[ax]) == 0ull) continue;
             double ssat = 0.0, qfree = 0.0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const bool sat = tau[ax] * aa[r] >= h; ssat += sat ? aa[r] : 0.0; qfree += sat ? 0.0 : a[r] * a[r]; }
+            for (int r = 0; r < R; ++r) { const bool sat = tau[ax] * fabs(a[r]) >= h; ssat += sat ? fabs(a[r]) : 0.0; const double a2 = a[r] * a[r]; qfree += sat ? 0.0 : a2; }
             ssat = Grp<LPI>::sum(ssat); qfree = Grp<LPI>::sum(qfree);
             if (live[ax]) {
                 ++its[ax];
-                const double rem = Tq[ax] - h * ssat;
+                const double rem = fma(-h, ssat, Tq[ax]);
                 if (!(qfree > 0.0)) {                                         // everything saturated
-                    if (rem > h * ssat * 1e-12 + 1e-300) st3 |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
+                    if (rem > fma(h * ssat, 1e-12, 1e-300)) st3 |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
                     tau[ax] = INFINITY; live[ax] = false;
                 } else {
                     const double tn = rem * frcp(qfree);
@@ -1356,26 +1399,27 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
         }
     }
 
+    STAMP(4);                                         // knapsack Newton done
     // ---- lane 0 of the group finishes the instance: integration (MPCSolver.cpp:274-278, 406-422)
     o.x = x0; o.y = y0; o.z = z0; o.xd = xd0; o.yd = yd0; o.zd = zd0;
     o.uz0 = 0.0; o.ux0 = 0.0; o.uy0 = 0.0; o.itx = 0; o.ity = 0;
     if (li == 0 && run) {
         o.uz0 = u[0];
-        o.z = z0 + dt * zd0;
-        o.zd = zd0 + c.dt_over_mass * o.uz0 - dt * c.g;
+        o.z = fma(dt, zd0, z0);
+        o.zd = fma(c.dt_over_mass, o.uz0, zd0) - dt * c.g;
         if (isnan(o.z)) { o.z = c.h_des; status |= ISMPC_ST_Z_NAN; }
         if (isnan(o.zd)) { o.zd = 0.0; status |= ISMPC_ST_Z_NAN; }
         const double A0a = 1.0 + ch1[0], A0b = s1[0], A0c = s2[0];
         if (lam0_l > c.gate) {                                            // MPCSolver.cpp:322
             status |= st3; o.itx = its[0]; o.ity = its[1];
             const double sa0 = (a[0] < 0.0) ? -1.0 : 1.0;
-            o.ux0 = mx0 + sgx * sa0 * ((aa[0] > 0.0) ? fmin(tau[0] * aa[0], h) : 0.0);
-            o.uy0 = my0 + sgy * sa0 * ((aa[0] > 0.0) ? fmin(tau[1] * aa[0], h) : 0.0);
+            o.ux0 = fma(sgx * sa0, (fabs(a[0]) > 0.0) ? fmin(tau[0] * fabs(a[0]), h) : 0.0, mx0);
+            o.uy0 = fma(sgy * sa0, (fabs(a[0]) > 0.0) ? fmin(tau[1] * fabs(a[0]), h) : 0.0, my0);
         } else status |= ISMPC_ST_FLIGHT;
-        o.x  = (A0a * x0 + A0b * xd0) + (1.0 - A0a) * o.ux0;
-        o.xd = (A0c * x0 + A0a * xd0) - A0c * o.ux0;
-        o.y  = (A0a * y0 + A0b * yd0) + (1.0 - A0a) * o.uy0;
-        o.yd = (A0c * y0 + A0a * yd0) - A0c * o.uy0;
+        o.x  = fma(1.0 - A0a, o.ux0, fma(A0a, x0, A0b * xd0));
+        o.xd = fma(-A0c, o.ux0, fma(A0c, x0, A0a * xd0));
+        o.y  = fma(1.0 - A0a, o.uy0, fma(A0a, y0, A0b * yd0));
+        o.yd = fma(-A0c, o.uy0, fma(A0c, y0, A0a * yd0));
     }
     o.status = status;
     if (u_traj_inst) {
@@ -1387,8 +1431,8 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
                 double vx = 0.0, vy = 0.0;
                 if (stage3) {
                     const double sa = (a[r] < 0.0) ? -1.0 : 1.0;
-                    vx = c.midx[idx + n] + sgx * sa * ((aa[r] > 0.0) ? fmin(tau[0] * aa[r], h) : 0.0);
-                    vy = c.midy[idx + n] + sgy * sa * ((aa[r] > 0.0) ? fmin(tau[1] * aa[r], h) : 0.0);
+                    vx = fma(sgx * sa, (fabs(a[r]) > 0.0) ? fmin(tau[0] * fabs(a[r]), h) : 0.0, c.midx[idx + n]);
+                    vy = fma(sgy * sa, (fabs(a[r]) > 0.0) ? fmin(tau[1] * fabs(a[r]), h) : 0.0, c.midy[idx + n]);
                 }
                 u_traj_inst[n] = run ? u[r] : 0.0; u_traj_inst[N + n] = vx; u_traj_inst[2 * N + n] = vy;
             }
@@ -1421,23 +1465,26 @@ template <int R, int LPI>
 __device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_raw, const int batch, const int lane,
                                                 const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                                                 ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
-                                                int rollout_frame, unsigned char* zmark, int launch_id)
+                                                int rollout_frame, unsigned char* zmark, int launch_id, double2* __restrict__ lds_wave)
 {
     const bool valid = gi_raw < batch;
     const int gi = valid ? gi_raw : batch - 1;        // tail groups recompute the last instance and store nothing
+    STAMP_DECL;
+    STAMP(0);                                         // first instructions of the wavefront
     const ismpc_tick_in* rec = ((rollout_frame >= 0) ? state_rw : in_ro) + gi;
     QState s;
     s.w = load_walk(c, rec, rollout_frame);
     s.x = rec->com_pos[0]; s.y = rec->com_pos[1]; s.z = rec->com_pos[2];
     s.xd = rec->com_vel[0]; s.yd = rec->com_vel[1]; s.zd = rec->com_vel[2];
     QOut o;
-    const bool deferred = tick_group_core<R, LPI>(c, lane, s, o, (u_traj && valid) ? u_traj + (size_t)gi * 3 * c.N : nullptr);
+    const bool deferred = tick_group_core<R, LPI>(c, lane, s, o, (u_traj && valid) ? u_traj + (size_t)gi * 3 * c.N : nullptr, lds_wave);
     if ((lane & (LPI - 1)) == 0 && valid) {
         if (out) store_record(out + gi, o);
         if (zmark) zmark[gi] = deferred ? 1 : 0;
         if (deferred) atomicMax(c.zflag, launch_id);
         if (rollout_frame >= 0 && !deferred) store_feedback(c, state_rw + gi, o, s.w);
     }
+    STAMP(5);                                         // stores issued
     return deferred && valid;
 }
 
@@ -1451,10 +1498,12 @@ void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, 
                      unsigned char* zmark, int launch_id)
 {
     constexpr int IPW = 64 / LPI;                      // instances per wavefront
+    __shared__ double2 lds_mid[ISMPC_QUAD_WAVES][wave_lds_double2<R, LPI>()];
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
     if (wave * IPW >= batch) return;
-    tick_group_body<R, LPI>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+    tick_group_body<R, LPI>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
 }
 
 // Latency variant for small batches (every wavefront resident at once): a wavefront that deferred one of its
@@ -1466,10 +1515,12 @@ void ismpc_tick_quad_inline(const DevConst c, const ismpc_tick_in* __restrict__ 
                             unsigned char* zmark, int launch_id)
 {
     constexpr int IPW = 64 / LPI;
+    __shared__ double2 lds_mid[ISMPC_QUAD_WAVES][wave_lds_double2<R, LPI>()];
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
     if (wave * IPW >= batch) return;
-    const bool def = tick_group_body<R, LPI>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+    const bool def = tick_group_body<R, LPI>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
     unsigned long long m = __builtin_amdgcn_ballot_w64(def);
     if (m == 0ull) return;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1493,8 +1544,10 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
                         int* __restrict__ stop_tick, int launch_id)
 {
     constexpr int IPW = 64 / LPI;
+    __shared__ double2 lds_mid[ISMPC_QUAD_WAVES][wave_lds_double2<R, LPI>()];
     const int lane = threadIdx.x & 63, li = lane & (LPI - 1);
-    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
     if constexpr (FB) { if (*c.zflag != launch_id) return; }
     const int nwork = FB ? batch : (batch + IPW - 1) / IPW;          // FB: one instance per wavefront (every group computes it, group 0 stores)
     for (int work = wave; work < nwork; work += FB ? (int)gridDim.x * ISMPC_QUAD_WAVES : nwork) {
@@ -1517,7 +1570,7 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
             if (s.w.fc >= 0 && s.w.fc < c.rows && s.w.sim >= c.ftsp_t[s.w.fc] - 1) { s.w.ctl = 0; s.w.mpc = 0; s.w.fc = s.w.fc + 1; }
             s.w.sim = (double)frame;
             QOut o;
-            const bool def = tick_group_core<R, LPI>(c, lane, s, o, nullptr);
+            const bool def = tick_group_core<R, LPI>(c, lane, s, o, nullptr, lds_mid[wv]);
             const bool park = def && alive;
             if (li == 0 && valid && alive && !def && traj) store_record(traj + (size_t)t * batch + gi, o);
             // a deferred instance: its pre-tick state goes to memory (FB = false: to stay there; FB = true: for the fallback body)
@@ -1819,6 +1872,23 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
         rc = upload(h, vq, &c.vq);
         if (rc == ISMPC_OK) rc = upload(h, tzg, &c.tzg);
         if (rc == ISMPC_OK) rc = upload(h, mxy, &c.midxy);
+        if (rc == ISMPC_OK && t.p.N <= 128) {
+            // lane-contiguous copies for the lane-group kernels' shape (sample li*R + r of pattern p)
+            const int lpi = h->lpi, R = quad_R(t.p.N, lpi);
+            std::vector<double> vqT(npp * (size_t)R * 3 * lpi * 2), tzgT((size_t)R * lpi * 2);
+            for (size_t pp = 0; pp < npp; ++pp)
+                for (int r = 0; r < R; ++r)
+                    for (int k = 0; k < 3; ++k)
+                        for (int li = 0; li < lpi; ++li) {
+                            const int n = li * R + r;                       // < 128 <= NT
+                            const size_t dst = (((pp * R + r) * 3 + k) * lpi + li) * 2;
+                            vqT[dst] = vq[(pp * NTq + n) * 6 + 2 * k]; vqT[dst + 1] = vq[(pp * NTq + n) * 6 + 2 * k + 1];
+                        }
+            for (int r = 0; r < R; ++r)
+                for (int li = 0; li < lpi; ++li) { const int n = li * R + r; tzgT[((size_t)r * lpi + li) * 2] = t.tz[n]; tzgT[((size_t)r * lpi + li) * 2 + 1] = t.tg[n]; }
+            rc = upload(h, vqT, &c.vqT);
+            if (rc == ISMPC_OK) rc = upload(h, tzgT, &c.tzgT);
+        }
     }
     c.flat = t.flat ? 1 : 0;
     if (rc != ISMPC_OK) { ismpc_destroy(h); return rc; }
@@ -1932,6 +2002,15 @@ int ismpc_reserve(ismpc_handle* h, int max_batch)
     }
     return ISMPC_OK;
 }
+
+#ifdef ISMPC_STAMPS
+int ismpc_debug_stamps(unsigned long long* dst, int reset)
+{
+    if (dst && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16384 * 8) != hipSuccess) return -2;
+    if (reset) { std::vector<unsigned long long> z(16384 * 8, 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z.data(), z.size() * 8) != hipSuccess) return -2; }
+    return 0;
+}
+#endif
 
 int ismpc_get_params(const ismpc_handle* h, ismpc_params* out)
 {

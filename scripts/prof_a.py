@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase shader-clock breakdown of the Formulation A wave kernel (library built with -DISMPC_A_PROF).
-usage: python -c "from quadruped_gait_generation_ismpc_amd import build; build.build(out='gpurun_out/variants/libismpc_prof.so', flags='-DISMPC_A_PROF')"
-       ISMPC_LIB=gpurun_out/variants/libismpc_prof.so python scripts/prof_a.py a_walk_C100"""
+usage: python -c "from quadruped_gait_generation_ismpc_amd import build; build.build(out='build/variants/libismpc_prof.so', flags='-DISMPC_A_PROF')"
+       ISMPC_LIB=build/variants/libismpc_prof.so python scripts/prof_a.py a_walk_C100"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

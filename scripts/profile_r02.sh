@@ -11,13 +11,13 @@ LEGS=${@:-headline shard_b8192 config1_b1024 config3_walk_C150 config4_mc_C200}
 for spec in $LEGS; do
   leg=${spec%%:*}; dt=f64; [[ $spec == *:* ]] && dt=${spec##*:}
   case $leg in
-    headline)      key=headline_b65536; kern=ismpc_tick_quad; batch=65536; steps=40 ;;
-    shard_b8192)   key=shard_b8192;     kern=ismpc_tick_quad; batch=8192;  steps=40 ;;
-    config1_b1024) key=config1_b1024;   kern=ismpc_tick_quad; batch=1024;  steps=40 ;;
-    *)             key=$leg;            kern=ismpc_a_tick_wave; batch=16384; steps=5 ;;
+    headline)      key=headline_b65536; kern='ismpc_tick_quad<'; batch=65536; steps=40 ;;
+    shard_b8192)   key=shard_b8192;     kern='ismpc_tick_quad_inline<'; batch=8192;  steps=40 ;;
+    config1_b1024) key=config1_b1024;   kern='ismpc_tick_quad_inline<'; batch=1024;  steps=40 ;;
+    *)             key=$leg;            kern='ismpc_a_tick_wave<'; batch=16384; steps=5 ;;
   esac
   [[ $dt != f64 ]] && key=${key}_$dt
-  CMD="python3 $R/bench.py --only $leg --dtype $dt --no-cpu-baseline --steps $steps --warmup 3 --min-region-ms 5"
+  CMD="python3 $R/bench.py --only $leg --dtype $dt --no-cpu-baseline --no-extras --steps $steps --warmup 3 --min-region-ms 5"
   echo "== $key"
   rm -rf $OUT/tmp_$key; mkdir -p $OUT/tmp_$key
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp_$key/stats -- $CMD > $OUT/${key}_bench_line.json 2> $OUT/tmp_$key/stats.err || { tail -5 $OUT/tmp_$key/stats.err; exit 1; }
@@ -25,9 +25,10 @@ for spec in $LEGS; do
   run() { name=$1; shift; timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/tmp_$key/$name -- $CMD > $OUT/tmp_$key/$name.json 2> $OUT/tmp_$key/$name.err || { tail -5 $OUT/tmp_$key/$name.err; exit 1; }; }
   run valu SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM
   run busy SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_F64
+  run mem TA_TA_BUSY_sum TA_FLAT_LOAD_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE
   run fetch FETCH_SIZE
   run write WRITE_SIZE
-  python3 $R/scripts/pmc_summary.py $OUT/tmp_$key $kern $OUT/pmc_$key.json batch=$batch leg=\"$key\" > /dev/null
+  python3 $R/scripts/pmc_summary.py $OUT/tmp_$key "$kern" $OUT/pmc_$key.json batch=$batch leg=\"$key\" > /dev/null
   grep -E "valu_insts_per_wave|hbm_bytes_per_launch|wave_cycles_per_wave" $OUT/pmc_$key.json | tr -d '\n'; echo
   head -3 $OUT/${key}_kernel_stats.csv | cut -c1-160
   rm -rf $OUT/tmp_$key/*/*/*agent_info.csv
