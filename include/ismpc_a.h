@@ -122,6 +122,14 @@ int ismpc_a_tick_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state
  * instance ended the previous tick with (moved by one sample); the optimum is the same, the route shorter. */
 int ismpc_a_rollout_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, int ticks,
                            ismpc_a_out* out_traj_dev, void* stream);
+/* Arithmetic type of the QP solve: fp32 = 0 (default) solves in fp64, fp32 = 1 in fp32 -- the dtype BASELINE.json names
+ * for its walking-gait and Monte-Carlo configurations.  In both cases the QP is posed relative to the current footstep
+ * (every number the solver touches is step-sized), its right-hand sides are formed in fp64 from the fp64 state, and the
+ * LIP update of the state (quad_walk_no_plots.m:297-322) is fp64; with fp32 = 1 the active-set iterations, the small
+ * linear systems and the returned u0 / f0 carry fp32 rounding (relative CoM error of a tick stays below 1e-6: a tick moves
+ * the CoM by B_upd u0 with |B_upd| ~ 1e-6..1e-3).  Needs 3 <= F <= 6. */
+int ismpc_a_set_precision(ismpc_a_handle* h, int fp32);
+
 /* The same first guess for caller-driven loops of ismpc_a_tick_batch*_device: enable it when instance i of one call is
  * instance i of the previous one (a wrong guess costs time, never accuracy).  Off by default. */
 int ismpc_a_set_warm_history(ismpc_a_handle* h, int enabled);

@@ -38,18 +38,31 @@ def _stale(target, sources, flags):
 
 def build(force=False, verbose=False, out=None, flags=None):
     """out: alternative output path (tuning sweeps build their variants there and load them with ISMPC_LIB=<path>; the
-    in-tree default library is never overwritten by a variant).  flags: extra hipcc flags (default: $ISMPC_HIPCC_FLAGS)."""
+    in-tree default library is never overwritten by a variant).  flags: extra hipcc flags (default: $ISMPC_HIPCC_FLAGS).
+    The translation units are compiled side by side (the Formulation A wave kernels are one unit per rows-per-lane value)."""
     target = out or LIB_HIP
     flags = os.environ.get("ISMPC_HIPCC_FLAGS", "") if flags is None else flags
     if out is None and flags.strip():
         raise RuntimeError("non-default compiler flags need an explicit output path: build(out=..., flags=...) and ISMPC_LIB=<out>")
-    hip_src = [os.path.join(CSRC, "ismpc_hip.hip"), os.path.join(CSRC, "ismpc_a_hip.hip"), os.path.join(CSRC, "ismpc_tables.cpp")]
-    deps = hip_src + [os.path.join(CSRC, "ismpc_tables.hpp"), os.path.join(ROOT, "include", "ismpc.h"),
-                      os.path.join(ROOT, "include", "ismpc_a.h")]
+    units = ["ismpc_hip.hip", "ismpc_a_hip.hip", "ismpc_a_wave_rl2.hip", "ismpc_a_wave_rl3.hip", "ismpc_a_wave_rl4.hip", "ismpc_tables.cpp"]
+    hip_src = [os.path.join(CSRC, u) for u in units]
+    deps = hip_src + [os.path.join(CSRC, h) for h in ("ismpc_tables.hpp", "ismpc_a_dev.hpp", "ismpc_a_wave.hpp")] + \
+        [os.path.join(ROOT, "include", "ismpc.h"), os.path.join(ROOT, "include", "ismpc_a.h")]
     quiet = None if verbose else subprocess.DEVNULL
     if force or _stale(target, deps, flags):
-        subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-I", os.path.join(ROOT, "include")] + flags.split() + hip_src + ["-o", target], stdout=quiet)
+        objdir = os.path.join(ROOT, "build", "obj", os.path.basename(target))
+        os.makedirs(objdir, exist_ok=True)
+        common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include")] + flags.split()
+        procs = []
+        for src in hip_src:
+            obj = os.path.join(objdir, os.path.basename(src) + ".o")
+            procs.append((src, obj, subprocess.Popen(common + ["-c", src, "-o", obj], stdout=quiet)))
+        objs = []
+        for src, obj, pr in procs:
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, f"hipcc -c {src}")
+            objs.append(obj)
+        subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", target], stdout=quiet)
         with open(target + ".flags", "w") as f:
             f.write(flags)
     return target

@@ -1,0 +1,40 @@
+// Shared by the Formulation A translation units: the per-handle device constants and the launch record the host side
+// (ismpc_a_hip.hip) hands to the wavefront-per-QP kernels (ismpc_a_wave.hpp, one translation unit per rows-per-lane value so
+// that hipcc compiles them side by side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/ismpc_a.h"
+
+namespace ismpc_a {
+
+constexpr int WG = 256;                // threads per workgroup; requires C + F <= 256
+constexpr int MAXF = 8;
+
+struct DevA {
+    int C, P, F, step, ds, n_gait, ncl, ldq, max_iter, sinv_in_lds;
+    int warm_add, warm_drop, warm_extra; // block warm start of the wave kernel: passes that add + drop rows, passes that only drop, re-entries
+    double dt, eta, w, Qf, disp_forw, disp_forw_dummy, disp_L, aa, wP, sumw;
+    double Au[9], Bu[3];
+    const double *a, *PA, *PA2, *wtail; // stability row, prefix sums PA[i] = sum_{k<i} a_k and PA2[i] = sum_{k<i} a_k^2, tail weights (index i-(C+1))
+    const double *fsx, *fsy;           // base plan, 0-based (fs_plan(k+1))
+    const double *clx0, *cly0, *clx1, *cly1;   // centreline: initial / rebuilt structure, 0-based (cl(k+1))
+    double* scratch;                   // per-workgroup S^-1 : ldq x ldq doubles each
+    const double *plan_x[4], *plan_y[4]; int nplans; double grav;   // base plans selectable per instance (ismpc_a_inst.plan)
+};
+
+// One launch of the wavefront-per-QP kernel.  precision: 0 = the QP is solved in fp64, 1 = in fp32 (state, right-hand sides
+// and the LIP update stay fp64).
+struct WaveLaunch {
+    const DevA* c_dev; int F;                      // the handle's constants in device memory; footsteps in the horizon (kernel shape)
+    const ismpc_a_state* prev; ismpc_a_state* state; const ismpc_a_inst* inst; const double* push; ismpc_a_out* out;
+    int batch; int* work_counter; unsigned long long* hist; int hist_load;
+    int precision; int cus; int* occ_cache;       // occ_cache: 4 ints per handle (precision x per-instance), 0 = not queried yet
+    hipStream_t stream;
+};
+
+// Implemented in ismpc_a_wave_rl{2,3,4}.hip.  Return 0, -1 (no instantiation for this F) or -2 (HIP error, *err set).
+int launch_wave_rl2(const WaveLaunch& L, hipError_t* err);
+int launch_wave_rl3(const WaveLaunch& L, hipError_t* err);
+int launch_wave_rl4(const WaveLaunch& L, hipError_t* err);
+
+}  // namespace ismpc_a

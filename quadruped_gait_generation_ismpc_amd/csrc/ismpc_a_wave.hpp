@@ -1,0 +1,1204 @@
+// Wavefront-per-QP kernel of Formulation A: the STRUCTURED dual active-set solver (scripts/proto_structured.py is its numpy
+// model).  Included by one translation unit per rows-per-lane value (ismpc_a_wave_rl{2,3,4}.hip).
+//
+// The per-axis QP of one instance (walking/quad_walk_no_plots.m:153-293):
+//     min 1/2 |u|^2 + Qf/2 |f - p|^2      u = ZMP velocities (C), f = footsteps (F)
+//     s.t. a'u = b                          stability (anticipative tail)          (:227-242)
+//          lo_i <= dt cumsum(u)_i - M_i f <= hi_i     ZMP band around the mapped footstep  (:153-181)
+//          -bl_r <= f_r - f_{r-1} <= bu_r             kinematic                           (:187-222)
+//
+// No matrix over the working set exists.  For the active ZMP rows, sorted by sample index i_1 < i_2 < ..., the Gram block in
+// the H^-1 metric is dt^2 min(i_j, i_k) + (footstep coupling)/Qf.  dt^2 min(.,.) is the covariance of a random walk, so its
+// inverse is TRIDIAGONAL: (K^-1 y)_j = (y_j - y_prev)/g_j - (y_next - y_j)/g_next with g the index gaps -- each active row
+// only needs its previous / next active row -- and K^-1 applied to a kernel column min(i+, .) is linear interpolation at i+
+// (two non-zeros).  Everything else -- the footstep coupling M~ (F columns), the stability row and the F kinematic rows -- is
+// a rank <= 2F+1 border: V_i = [M~_i, dt PA_i, Bk_i] has a closed form per row, G = V' K^-1 V / dt^2 (m x m, m = 2F+1) is kept
+// by +/- one outer product per gap created/destroyed, and one quasi-definite m x m system per step gives the border unknowns.
+// Step lengths, add / drop logic and termination are Goldfarb-Idnani's.  Lanes own RL consecutive rows (row = ZMP sample), so
+// the primal direction is "own multiplier as an impulse + one suffix scan" with no scatter; wave collectives are DPP scans.
+//
+// Coordinates: every position of the QP (ZMP, footsteps, plan) is taken RELATIVE TO THE CURRENT FOOTSTEP.  The mapping rows sum
+// to one, so the band of every row becomes the same pair of numbers (-(zmp - cur) -+ w/2), the first kinematic row becomes
+// symmetric, and all quantities the solver touches are step-sized: that is what lets the same code run in fp32 (Real = float:
+// right-hand sides are formed in fp64 and rounded once; the LIP update of the state stays fp64) as well as in fp64.
+//
+// Register budget: per row a lane keeps u, the mapping weight, the multiplier (Real), a float norm, and two packed ints
+// (first mapped footstep + state; previous / next active row).  The bounds are two wave-uniform numbers.
+#pragma once
+#include <cmath>
+#include <algorithm>
+#include "ismpc_a_dev.hpp"
+
+namespace ismpc_a {
+
+// ---- precision traits ---------------------------------------------------------------------------------------------------
+template <typename R> struct Num;
+template <> struct Num<double> {
+    static constexpr double viol_rel = 1e-11, viol_abs = 1e-13;     // a row is violated beyond  rel (|v| + |bounds|) + abs
+    static constexpr double bound_rel = 1e-8, bound_abs = 1e-10;    // block solve: active rows must sit on their bounds
+    static constexpr double eq_rel = 1e-8;                          // ... and the stability row must hold
+    static constexpr double gamma_rel = 1e-12;                      // full step possible when gamma > rel |n+|^2
+    static constexpr double final_rel = 1e-7, final_abs = 1e-9;     // check of the returned point
+    static constexpr double mult_rel = 1e-8;                        // polish: multipliers may be this negative
+};
+template <> struct Num<float> {
+    static constexpr float viol_rel = 2e-6f, viol_abs = 2e-6f;
+    static constexpr float bound_rel = 1e-4f, bound_abs = 1e-5f;
+    static constexpr float eq_rel = 1e-4f;
+    static constexpr float gamma_rel = 2e-6f;
+    static constexpr float final_rel = 2e-4f, final_abs = 2e-5f;
+    static constexpr float mult_rel = 1e-4f;
+};
+
+// ---- wave primitives, both precisions -------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, bool BOUND_ZERO>
+__device__ __forceinline__ double dppv(double old, double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, 0xf, BOUND_ZERO);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, 0xf, BOUND_ZERO);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK, bool BOUND_ZERO>
+__device__ __forceinline__ float dppv(float old, float src)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, BOUND_ZERO));
+}
+template <int CTRL, int RM> __device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xf, false); }
+
+template <typename R> __device__ __forceinline__ R wave_scan_up(R v)       // inclusive prefix sum over the 64 lanes
+{
+    v += dppv<0x111, 0xf, true>(R(0), v);
+    v += dppv<0x112, 0xf, true>(R(0), v);
+    v += dppv<0x114, 0xf, true>(R(0), v);
+    v += dppv<0x118, 0xf, true>(R(0), v);
+    v += dppv<0x142, 0xa, false>(R(0), v);
+    v += dppv<0x143, 0xc, false>(R(0), v);
+    return v;
+}
+__device__ __forceinline__ double rl(double v, int l)
+{
+    const int ll = __builtin_amdgcn_readfirstlane(l);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), ll), __builtin_amdgcn_readlane(__double2loint(v), ll));
+}
+__device__ __forceinline__ float rl(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(l))); }
+__device__ __forceinline__ int rl(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+template <typename R> __device__ __forceinline__ R wave_sum(R v) { return rl(wave_scan_up(v), 63); }
+template <typename R> __device__ __forceinline__ R wave_min(R v)
+{
+    const R inf = R(INFINITY);
+    v = fmin(v, dppv<0x111, 0xf, false>(inf, v)); v = fmin(v, dppv<0x112, 0xf, false>(inf, v));
+    v = fmin(v, dppv<0x114, 0xf, false>(inf, v)); v = fmin(v, dppv<0x118, 0xf, false>(inf, v));
+    v = fmin(v, dppv<0x142, 0xa, false>(inf, v)); v = fmin(v, dppv<0x143, 0xc, false>(inf, v));
+    return rl(v, 63);
+}
+__device__ __forceinline__ int wave_scan_max_i(int v)      // inclusive prefix maximum over the 64 lanes
+{
+    const int lo = -2147483647 - 1;
+    v = max(v, dpp_i<0x111, 0xf>(lo, v)); v = max(v, dpp_i<0x112, 0xf>(lo, v)); v = max(v, dpp_i<0x114, 0xf>(lo, v));
+    v = max(v, dpp_i<0x118, 0xf>(lo, v)); v = max(v, dpp_i<0x142, 0xa>(lo, v)); v = max(v, dpp_i<0x143, 0xc>(lo, v));
+    return v;
+}
+// 1/x to rounding error: hardware reciprocal + Newton (the IEEE division sequence is more than twice as long, and the
+// active-set loop divides by gaps and pivots on its critical path)
+__device__ __forceinline__ double frcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ float frcp(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
+__device__ __forceinline__ float rsq_f(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// Sums of K per-lane values over the 64 lanes (wave_fold_sums below).  Values are folded pairwise: after a step with partner
+// lane ^ 2^s a lane keeps half of its values (the half its partner sent sums for), so K values cost about K + 6 exchange-adds
+// instead of 6 K.
+template <typename R, int XOR> __device__ __forceinline__ R lane_xor(R v);
+template <> __device__ __forceinline__ float lane_xor<float, 1>(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, false)); }
+template <> __device__ __forceinline__ float lane_xor<float, 2>(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, false)); }
+template <> __device__ __forceinline__ float lane_xor<float, 4>(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F)); }   // xor_mask 4, and_mask 0x1f
+template <> __device__ __forceinline__ float lane_xor<float, 8>(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, false)); }   // row_ror:8
+template <> __device__ __forceinline__ float lane_xor<float, 16>(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); }  // xor_mask 16
+template <> __device__ __forceinline__ float lane_xor<float, 32>(float v) { return __shfl_xor(v, 32); }
+template <int XOR> __device__ __forceinline__ double lane_xor_d(double v)
+{
+    return __hiloint2double(__float_as_int(lane_xor<float, XOR>(__int_as_float(__double2hiint(v)))),
+                            __float_as_int(lane_xor<float, XOR>(__int_as_float(__double2loint(v)))));
+}
+template <> __device__ __forceinline__ double lane_xor<double, 1>(double v) { return lane_xor_d<1>(v); }
+template <> __device__ __forceinline__ double lane_xor<double, 2>(double v) { return lane_xor_d<2>(v); }
+template <> __device__ __forceinline__ double lane_xor<double, 4>(double v) { return lane_xor_d<4>(v); }
+template <> __device__ __forceinline__ double lane_xor<double, 8>(double v) { return lane_xor_d<8>(v); }
+template <> __device__ __forceinline__ double lane_xor<double, 16>(double v) { return lane_xor_d<16>(v); }
+template <> __device__ __forceinline__ double lane_xor<double, 32>(double v) { return lane_xor_d<32>(v); }
+
+// N values per lane (N a power of two), partner lane ^ X: a lane whose X bit is clear keeps the even members, the other the
+// odd ones; each kept member becomes own + partner's.  After log2 N steps one value is left: the sum, over the 2^log2 N lanes
+// that differ in the bits used so far, of member (lane & (N0 - 1)) of the original N0 values.
+template <typename R, int N, int X>
+__device__ __forceinline__ R fold_pow2(const R* v, const int lane)
+{
+    if constexpr (N == 1) return v[0];
+    else {
+        const bool hi = (lane & X) != 0;
+        R w[N / 2];
+#pragma unroll
+        for (int j = 0; j < N / 2; ++j) {
+            const R keep = hi ? v[2 * j + 1] : v[2 * j], send = hi ? v[2 * j] : v[2 * j + 1];
+            w[j] = keep + lane_xor<R, X>(send);
+        }
+        return fold_pow2<R, N / 2, X * 2>(w, lane);
+    }
+}
+template <typename R, int X> __device__ __forceinline__ R finish_sum(R v)     // plain butterfly over the remaining lane bits
+{
+    if constexpr (X <= 32) { v += lane_xor<R, X>(v); return finish_sum<R, X * 2>(v); }
+    else return v;
+}
+// out[t] = sum over the wavefront of acc[t], t < NS (NS <= 63): the binary digits of NS give chunks of 32 / 16 / ... / 1 values
+template <typename R, int NS, int P, int OFF>
+__device__ __forceinline__ void wave_fold_sums_from(const R* acc, R* out, const int lane)
+{
+    if constexpr (P >= 0) {
+        constexpr int N = 1 << P;
+        if constexpr ((NS & N) != 0) {
+            const R part = fold_pow2<R, N, 1>(acc + OFF, lane);
+            const R tot = finish_sum<R, N>(part);
+            if (lane < N) out[OFF + lane] = tot;
+            wave_fold_sums_from<R, NS, P - 1, OFF + N>(acc, out, lane);
+        } else wave_fold_sums_from<R, NS, P - 1, OFF>(acc, out, lane);
+    }
+}
+template <typename R, int NS> __device__ __forceinline__ void wave_fold_sums(const R* acc, R* out, const int lane)
+{
+    static_assert(NS >= 1 && NS < 64, "chunk decomposition covers 1..63 sums");
+    wave_fold_sums_from<R, NS, 5, 0>(acc, out, lane);
+}
+
+// ---- per-wavefront LDS.  Small vectors (length m = 2F+1 or F+2) are kept ONE ELEMENT PER LANE in registers and mirrored here
+// when other lanes need them by index; nothing of size "working set" is stored anywhere.
+template <typename R, int F> struct WaveLds {
+    static constexpr int m = 2 * F + 1;
+    static constexpr int NTH = F * (F + 1) / 2 + 2 * F + 2;
+    R     sv[WG];                      // V_row . y of every ZMP row
+    R     w1s[WG];                     // mapping weight of every row (wave-uniform look-ups by row index)
+    unsigned char k1s[WG];             // first mapped footstep of every row
+    R     comb[F + 2];                 // footstep-column coefficients seen by a row: comb[k1], comb[k1+1]
+    R     fl[F + 2];                   // f[0..F+1] with fl[0] = fl[F+1] = 0 (relative to the current footstep)
+    R     pf[F + 2];                   // the plan's footsteps (same layout): block warm start
+    R     th[NTH];                     // Gram sums of the block warm start: Theta (upper triangle), psi, gamma, sigma, gamma_E
+    R     G[m * m];                    // V' K^-1 V / dt^2 over the active ZMP rows
+    R     vp[m], hx[m], d1[m], d2[m], d0[m], cc[m], mt[m];
+};
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// value held by the owner of ZMP row `row` (1-based, wave-uniform) in a per-row register array
+template <typename V, int RL> __device__ __forceinline__ V at_row(const V (&v)[RL], int row)
+{
+    const int o = (row - 1) / RL, k = (row - 1) - o * RL;
+    V x = v[0];
+#pragma unroll
+    for (int r = 1; r < RL; ++r) if (k == r) x = v[r];
+    return rl(x, o);
+}
+// element `e` (this lane's) of the border row V = [M~ (F), dt PA, Bk (F)] of a ZMP row with mapping (k1, w1, 1-w1), PA = pa
+template <typename R, int F> __device__ __forceinline__ R border_elem(int e, int k1, R w1, R pa, R dt, R isq)
+{
+    if (e == F) return dt * pa;
+    const R w2 = R(1) - w1;
+    const int r = e < F ? e + 1 : e - F;                  // footstep column 1..F
+    const R mr = (r == k1) ? w1 : ((r == k1 + 1) ? w2 : R(0));
+    if (e < F) return mr * isq;
+    const R mp = (r - 1 >= 1) ? ((r - 1 == k1) ? w1 : ((r - 1 == k1 + 1) ? w2 : R(0))) : R(0);
+    return (-mr + mp) * isq;
+}
+
+// centreline value cl(k0+1) without the table: quad_walk_no_plots.m:86-99 (initial structure) / :540-549 (rebuilt one),
+// linspace as MATLAB evaluates it.  Used when step / ds differ per instance.
+__device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int step, int ds, bool rebuilt, int k0)
+{
+    const int s = k0 / step, r = k0 - s * step, q = r - (step - ds);
+    const double d1 = fs[s];
+    if (q <= 0 || (rebuilt && s == 0)) return d1;
+    const double d2 = fs[s + 1];
+    if (q == ds - 1) return d2;
+    return d1 + ((double)q * (d2 - d1)) / (double)(ds - 1);
+}
+
+// Residency target (wavefronts per SIMD = workgroups per CU, 256 threads each): fp64 3 for two rows per lane and 2 beyond
+// (measured round 1: the 128-register budget of 4 per CU spills), fp32 4 / 3.
+template <typename R, int RL> constexpr int wave_min_blocks() { return sizeof(R) == 4 ? (RL <= 2 ? 4 : 3) : (RL <= 2 ? 3 : 2); }
+
+// RL = ZMP rows per lane (C <= 64 RL), F = footsteps in the horizon (m = 2F+1 border columns).
+// PI: per-instance gait parameters (ismpc_a_inst): height, Qf, step, ds, F <= the template F, base plan.
+template <typename R, int RL, int F, bool PI>
+__global__ __launch_bounds__(WG, (wave_min_blocks<R, RL>()))
+void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
+                       const ismpc_a_inst* __restrict__ ipar, const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch,
+                       int* __restrict__ work_counter, unsigned long long* __restrict__ hist, int hist_load)
+{
+    using NM = Num<R>;
+    const DevA& c = *cp;                                   // handle constants, read from memory where they are used (by value they would
+    constexpr int m = 2 * F + 1;                           // sit in 70 scalar registers for the whole persistent loop)
+    __shared__ WaveLds<R, F> lds_all[WG / 64];
+    __shared__ R a_s[WG], pa_s[WG + 1];                    // stability row and its prefix sums: same for every QP of the handle
+    __shared__ R a_pi[PI ? WG / 64 : 1][PI ? WG : 1], pa_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1];   // ... or one per wavefront
+    // the same prefix sums and those of a^2 in fp64, whatever the precision of the solve: the two places where the stability row
+    // is (nearly) in the span of the active ZMP rows are evaluated from them without cancellation (see gap_terms below)
+    __shared__ double pad_s[PI ? 1 : WG + 1], pa2d_s[PI ? 1 : WG + 1];
+    __shared__ double pad_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1], pa2d_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveLds<R, F>& L = lds_all[wv];
+    const int C = c.C, P = c.P;
+    const R dt = (R)c.dt, idt = (R)(1.0 / c.dt), idt2 = (R)(1.0 / (c.dt * c.dt));
+    const bool klane = lane >= 1 && lane <= F;            // lane r owns kinematic row r (and f_r)
+    if (!PI) {
+        for (int k = threadIdx.x; k <= C; k += WG) { pa_s[k] = (R)c.PA[k]; pad_s[k] = c.PA[k]; pa2d_s[k] = c.PA2[k]; if (k < C) a_s[k] = (R)c.a[k]; }
+        __syncthreads();
+    }
+    const R* ap = PI ? a_pi[PI ? wv : 0] : a_s;
+    const R* pap = PI ? pa_pi[PI ? wv : 0] : pa_s;
+    const double* pad = PI ? pad_pi[PI ? wv : 0] : pad_s;
+    const double* pa2d = PI ? pa2d_pi[PI ? wv : 0] : pa2d_s;
+
+    // QPs are claimed one at a time from a global counter: iteration counts differ a lot between instances
+    for (;;) {
+        int claimed = 0;
+        if (lane == 0) claimed = atomicAdd(work_counter, 1);
+        const int work = __builtin_amdgcn_readfirstlane(claimed);
+        if (work >= 2 * batch) break;
+        const int inst = work >> 1, axis = work & 1;
+        const ismpc_a_state st = state_in[inst];
+        const double pos = axis == 0 ? st.x : st.y;
+        const double vel = (axis == 0 ? st.xd : st.yd) + (push ? push[inst * 2 + axis] : 0.0);
+        const double zmp = axis == 0 ? st.xz : st.yz;
+        const double cur = axis == 0 ? st.cur_x : st.cur_y;
+        const double off = axis == 0 ? st.off_x : st.off_y;
+        const int j = st.j, fc = st.fc;
+        int status = 0;
+        // ---- gait parameters: the handle's, or this instance's
+        int step_ = c.step, ds_ = c.ds, Fi = F, plan = 0;
+        double Qf_d = c.Qf, eta = c.eta, aa_d = c.aa;
+        if (PI) {
+            const ismpc_a_inst ip = ipar[inst];
+            step_ = ip.step; ds_ = ip.ds; Fi = ip.F; plan = ip.plan; Qf_d = ip.Qf;
+            if (step_ < 2 || ds_ < 2 || ds_ >= step_ || Fi < 1 || Fi > F || plan < 0 || plan >= c.nplans || !(ip.height > 0) || !(Qf_d > 0)) {
+                status |= ISMPC_A_ST_BAD_INDEX; step_ = 2; ds_ = 1; Fi = 1; plan = 0; Qf_d = 1.0; eta = 1.0;
+            } else eta = sqrt(c.grav / ip.height);
+        }
+        const R Qf = (R)Qf_d, sq = (R)sqrt(Qf_d), isq = (R)(1.0 / sqrt(Qf_d)), iQf = (R)(1.0 / Qf_d);
+        const float rstep = 1.0f / (float)step_;
+        const double* fs = PI ? (axis == 0 ? c.plan_x[plan] : c.plan_y[plan]) : (axis == 0 ? c.fsx : c.fsy);
+        const double* cl = st.rebuilt ? (axis == 0 ? c.clx1 : c.cly1) : (axis == 0 ? c.clx0 : c.cly0);
+        const double cloff = st.rebuilt ? off : 0.0;
+        const int ncl = PI ? (c.n_gait - 1) * step_ : c.ncl;
+        if (fc < 1 || fc + Fi > c.n_gait || j < 1 || j + P > ncl || j < step_ * (fc - 1) || j > step_ * fc - 1)
+            status |= ISMPC_A_ST_BAD_INDEX;
+        // the band of EVERY row, relative to the current footstep (the mapping rows sum to one): -(zmp - cur) -+ w/2
+        const R zlo = (R)(-(zmp - cur) - c.w / 2), zhi = (R)(-(zmp - cur) + c.w / 2);
+        R aa = (R)aa_d;
+        if (PI) {
+            // stability row a_i (quad_walk_no_plots.m:233-238), its prefix sums and a'a for this instance's eta
+            R* aw = a_pi[PI ? wv : 0]; R* paw = pa_pi[PI ? wv : 0];
+            const double lam = exp(-eta * c.dt);
+            const double k1c = (1 / eta) * (1 - lam) / (1 - pow(lam, (double)C)), k2c = c.dt * 1.0 * exp(-eta * c.dt * C);
+            double* padw = pad_pi[PI ? wv : 0]; double* pa2dw = pa2d_pi[PI ? wv : 0];
+            double av[RL], cum[RL], cum2[RL], loc = 0.0, sqs = 0.0;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) {
+                const int i0 = lane * RL + k;
+                av[k] = (i0 < C) ? k1c * exp(-eta * c.dt * i0) - k2c : 0.0;
+                loc += av[k]; cum[k] = loc; sqs += av[k] * av[k]; cum2[k] = sqs;
+            }
+            const double base = wave_scan_up(loc) - loc, base2 = wave_scan_up(sqs) - sqs;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) {
+                const int i0 = lane * RL + k;
+                if (i0 < C) { aw[i0] = (R)av[k]; paw[i0 + 1] = (R)(base + cum[k]); padw[i0 + 1] = base + cum[k]; pa2dw[i0 + 1] = base2 + cum2[k]; }
+            }
+            if (lane == 0) { paw[0] = R(0); padw[0] = 0.0; pa2dw[0] = 0.0; }
+            aa = (R)wave_sum(sqs);
+            WAVE_LDS_SYNC();
+        }
+
+        // ---- per-row data: lane owns ZMP rows lane*RL+1 .. lane*RL+RL (row i = sample i, u index i-1).
+        // ks = first mapped footstep (bits 0-3) | row state + 1 (bits 4-5: 0 upper active, 1 free, 2 lower active);
+        // pn = previous active row (bits 0-15) | next active row (bits 16-31), kept for every row, active or not
+        R u[RL], w1[RL], mu[RL];
+            int ks[RL], pn[RL];
+#define K1_(k_)  (ks[k_] & 15)
+#define STA_(k_) (((ks[k_] >> 4) & 3) - 1)
+#define SET_STA_(k_, s_) (ks[k_] = (ks[k_] & 15) | (((s_) + 1) << 4))
+#define PRV_(k_) (pn[k_] & 0xffff)
+#define NXT_(k_) ((int)((unsigned)pn[k_] >> 16))
+#define SET_PRV_(k_, p_) (pn[k_] = (pn[k_] & ~0xffff) | (p_))
+#define SET_NXT_(k_, n_) (pn[k_] = (pn[k_] & 0xffff) | ((n_) << 16))
+        bool ovf = false;
+#pragma unroll
+        for (int k = 0; k < RL; ++k) {
+            const int i = lane * RL + k + 1;
+            u[k] = R(0); mu[k] = R(0); pn[k] = 0;
+            if (i <= C) {
+                int qd = (int)((float)(j + i) * rstep);                          // (j + i) / step_ without the integer-division sequence
+                if (qd * step_ > j + i) --qd; else if ((qd + 1) * step_ <= j + i) ++qd;
+                int pf = qd - fc + 1; if (pf < 0) pf = 0;
+                const int rem = step_ * (fc + pf) - (j + i);
+                w1[k] = (rem > ds_) ? R(1) : (R)((double)rem / ds_);             // mapping(i, pf+1); the next column gets 1 - w1
+                ovf = ovf || pf > Fi || (rem <= ds_ && pf + 1 > Fi);
+                if (pf > 15) pf = 15;
+                ks[k] = pf | (1 << 4);
+                L.k1s[i - 1] = (unsigned char)pf; L.w1s[i - 1] = w1[k];
+            } else { w1[k] = R(1); ks[k] = 1 << 4; }
+        }
+        if (__builtin_amdgcn_ballot_w64(ovf) != 0) status |= ISMPC_A_ST_OVERFLOW;
+        // anticipative tail (quad_walk_no_plots.m:227-231)
+        double tl = 0.0;
+        if (!(status & ISMPC_A_ST_BAD_INDEX)) {
+            if (PI) {
+                const double om = 1 - exp(-eta * c.dt);
+                for (int i = C + 1 + lane; i <= P; i += 64)
+                    tl += exp(-eta * c.dt * i) * om * ((cl_closed(fs, step_, ds_, st.rebuilt != 0, j + i - 1) + cloff) - cur);
+            } else
+                for (int i = C + 1 + lane; i <= P; i += 64) tl += c.wtail[i - (C + 1)] * ((cl[j + i - 1] + cloff) - cur);
+        }
+        double tail = wave_sum(tl);
+        if (!(status & ISMPC_A_ST_BAD_INDEX))
+            tail += PI ? exp(-eta * c.dt * P) * ((cl_closed(fs, step_, ds_, st.rebuilt != 0, P - 1) + cloff) - cur)
+                       : c.wP * ((cl[P - 1] + cloff) - cur);
+        const R beq = (R)(pos + vel / eta - zmp - tail);
+        // ---- kinematic row r and footstep f_r (relative to the current one) live in lane r (1..F); Khat_r = sqrt(Qf) (f_r - f_{r-1})
+        R fr = R(0), klo = R(-INFINITY), khi = R(INFINITY), muK = R(0);
+        int kact = 0;
+        if (klane) {
+            const int r = lane;
+            double bup = axis == 0 ? c.disp_forw : (c.disp_L / 2 + c.disp_L / 2);
+            if (fc == 1 && r == 1) bup = axis == 0 ? c.disp_forw_dummy : (c.disp_L / 2 + c.disp_L / 2);
+            khi = (R)bup; klo = (R)(-bup);                                       // f_1 - cur, f_r - f_{r-1}: symmetric in these coordinates
+            fr = (status & ISMPC_A_ST_BAD_INDEX) ? R(0) : (R)((fs[fc + r - 1] + off) - cur);
+            if (PI && r > Fi) { khi = R(INFINITY); klo = R(-INFINITY); fr = R(0); }   // beyond this instance's horizon: no variable, no row
+        }
+        const R knrm = (lane >= 2) ? sq * R(0.70710678118654752440) : sq;   // 1 / |K_r|_{H^-1}: |kvec_r|^2 = 2 (r >= 2) or 1
+        int iters = 0, qz = 0, qk = 0;
+        R muE = R(0);
+        bool done_opt = false;                                // the block passes ended on a checked optimum: nothing left to do
+        if (status == 0) {
+            // ---- equality first: u = (b / a'a) a
+            const R t0 = beq / aa;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; u[k] = (i <= C) ? t0 * ap[i - 1] : R(0); }
+            muE = t0;
+            for (int e = lane; e < m * m; e += 64) L.G[e] = R(0);
+            if (lane <= F + 1) L.pf[lane] = fr;
+            WAVE_LDS_SYNC();
+
+            // row values at the current point: v_i = dt cumsum(u)_i - M_i f, in vv[]; leaves f in L.fl
+            auto row_values = [&](R (&vv)[RL]) __attribute__((always_inline)) {
+                if (lane <= F + 1) L.fl[lane] = fr;
+                WAVE_LDS_SYNC();
+                R lc = R(0);
+#pragma unroll
+                for (int k = 0; k < RL; ++k) { lc += u[k]; vv[k] = lc; }
+                const R bs = wave_scan_up(lc) - lc;
+#pragma unroll
+                for (int k = 0; k < RL; ++k) vv[k] = dt * (vv[k] + bs) - (w1[k] * L.fl[K1_(k)] + (R(1) - w1[k]) * L.fl[K1_(k) + 1]);
+            };
+
+            // D = a'a - G_EE >= 0, the (stability, stability) entry of the small system with its sign flipped.  Both terms are sums
+            // over the same samples -- G_EE = sum over gaps (p, i] between consecutive active rows of (sum a)^2 / (i - p) -- and
+            // they cancel completely when every ZMP row is active (the stability row then lies in the span of the active rows
+            // but for the footstep coupling, which is 1/Qf small): formed as ONE sum of per-gap terms
+            //     [sum a^2 - (sum a)^2 / (i - p)]  +  (sum of a^2 past the last active row),
+            // each from the fp64 prefix sums, it is exact where it matters (a gap of one row contributes exactly 0).
+            auto stability_defect = [&]() __attribute__((always_inline)) -> R {
+                double dl = 0.0;
+#pragma unroll
+                for (int k = 0; k < RL; ++k) {
+                    const int i = lane * RL + k + 1;
+                    if (i <= C && STA_(k) != 0) {
+                        const int pv = PRV_(k);
+                        const double sa = pad[i] - pad[pv];
+                        dl += (pa2d[i] - pa2d[pv]) - sa * sa * frcp((double)(i - pv));
+                        if (NXT_(k) == 0) dl += pa2d[C] - pa2d[i];
+                    }
+                }
+                if (qz == 0 && lane == 0) dl = pa2d[C];
+                return (R)wave_sum(dl);
+            };
+            // mean of a over the samples p+1 .. j (consecutive active rows p < j), from the fp64 prefix sums
+            auto abar = [&](int p_, int j_) __attribute__((always_inline)) -> R { return (R)(pad[j_] - pad[p_]) * frcp((R)(j_ - p_)); };
+            R Dee = aa;
+
+            // ---- small quasi-definite system  [[I+G11, G1x],[Gx1, Gxx - Sxx]] cc = rhs (L.hx), G in L.G; unknown order:
+            // 0..F-1 footstep columns, F = stability row, F+1..2F = Khat_1..F (rows outside kmask: pinned to 0).  Returns
+            // this lane's cc[lane] and leaves cc in L.cc.
+            auto solve_small = [&](const unsigned long long kmask) __attribute__((always_inline)) -> R {
+                // lane i < m owns row i of the augmented matrix in registers; the pivot row travels by readlane: no LDS
+                // traffic and no barriers inside the elimination
+                const int i = lane < m ? lane : m - 1;
+                const bool ipin = i > F && !((kmask >> (i - F)) & 1ull);
+                R Tr[m + 1];
+#pragma unroll
+                for (int jj = 0; jj < m; ++jj) {
+                    R val = L.G[i * m + jj];
+                    if (jj < F && i == jj) val += R(1);
+                    if (jj == F && i == F) val = -Dee;                              // G_EE - a'a without the cancellation
+                    if (jj > F && i > F) {
+                        const int r1 = i - F, r2 = jj - F;
+                        val -= (r1 == r2) ? (r1 >= 2 ? R(2) : R(1)) : ((r1 - r2 == 1 || r2 - r1 == 1) ? R(-1) : R(0));
+                    }
+                    const bool jpin = jj > F && !((kmask >> (jj - F)) & 1ull);
+                    if (ipin || jpin) val = (i == jj) ? R(-1) : R(0);
+                    Tr[jj] = val;
+                }
+                Tr[m] = ipin ? R(0) : L.hx[i];
+#pragma unroll
+                for (int kk = 0; kk < m; ++kk) {                                 // Gauss-Jordan, no pivoting (quasi-definite)
+                    if (kk > F && !((kmask >> (kk - F)) & 1ull)) continue;       // pinned unknown: its column is already e_kk
+                    const R ipv = frcp(rl(Tr[kk], kk));
+                    const R fct = (lane == kk) ? R(0) : Tr[kk] * ipv;
+#pragma unroll
+                    for (int jj = kk + 1; jj <= m; ++jj) Tr[jj] -= fct * rl(Tr[jj], kk);
+                }
+                R dg = Tr[0];
+#pragma unroll
+                for (int jj = 1; jj < m; ++jj) if (lane == jj) dg = Tr[jj];
+                const R cc_e = (lane < m) ? Tr[m] * frcp(dg) : R(0);             // lane e: cc[e]
+                if (lane < m) L.cc[lane] = cc_e;
+                WAVE_LDS_SYNC();
+                return cc_e;
+            };
+
+            // ---- one structured solve for a whole working set (the ZMP rows in ks[], the kinematic rows in kmask / kact):
+            // minimiser u, f and all multipliers; leaves G(W) in L.G and prv / nxt of every row
+            auto block_solve = [&](const unsigned long long kmask) __attribute__((always_inline)) {
+                // ---- previous / next active row of every row (active or not): exclusive max scan, exclusive suffix min scan
+                int nact = 0;
+                R cvr[RL];
+                // active kinematic rows: right-hand sides sqrt(Qf) (bound_r - (p_r - p_{r-1})) travel to the lanes of their unknowns
+                if (klane) L.d1[lane - 1] = (kact != 0) ? sq * ((kact > 0 ? klo : khi) - (L.pf[lane] - L.pf[lane - 1])) : R(0);
+                {
+                    int lmax = 0, lmin = 1 << 30;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        const int sk = STA_(k);
+                        const bool act = i <= C && sk != 0;
+                        if (act) { lmax = max(lmax, i); lmin = min(lmin, i); }
+                        nact += __builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
+                        // c_i = bound_i + M_i . plan footsteps
+                        cvr[k] = act ? (sk > 0 ? zlo : zhi) + (w1[k] * L.pf[K1_(k)] + (R(1) - w1[k]) * L.pf[K1_(k) + 1]) : R(0);
+                        if (i <= C) L.sv[i - 1] = cvr[k];                    // c of every row, for its successor
+                    }
+                    int run = dpp_i<0x138, 0xf>(0, wave_scan_max_i(lmax));
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; SET_PRV_(k, run); if (i <= C && STA_(k) != 0) run = i; }
+                    const int rev = __shfl(lmin, 63 - lane);
+                    const int ex = dpp_i<0x138, 0xf>(1 << 30, -wave_scan_max_i(-rev));
+                    const int nx = __shfl(ex, 63 - lane);
+                    run = (nx == (1 << 30)) ? 0 : nx;
+#pragma unroll
+                    for (int k = RL - 1; k >= 0; --k) { const int i = lane * RL + k + 1; SET_NXT_(k, run); if (i <= C && STA_(k) != 0) run = i; }
+                }
+                WAVE_LDS_SYNC();
+                // ---- G = V'K^-1 V / dt^2 and g = V'K^-1 c / dt^2 as sums over consecutive active pairs (p, i) of
+                // d d' / gap, d = V_i - V_p.  V_i = Phi(theta_i) + dt PA_i e_E with theta_i the row's mapping weights over the
+                // F footstep columns and Phi a fixed sparse map, so everything follows from the Gram sums of
+                // [dtheta (F) | dt dPA | dc] weighted by 1 / (dt^2 gap): each lane adds its own rows, then the sums are folded
+                // over the wavefront (fold_step: about one exchange-add per sum instead of six).
+                {
+                    constexpr int NT = F * (F + 1) / 2, NR = 2 * F + 2;
+                    // two sweeps over the lane's rows -- Theta (NT sums), then psi, gamma, sigma, gamma_E (NR sums) -- keep the live
+                    // accumulators at max(NT, NR) instead of NT + NR; the per-row differences are cheap to form twice
+                    auto pair_diffs = [&](int k, R (&dth)[F], R& om, R& dE, R& dc) __attribute__((always_inline)) {
+                        const int i = lane * RL + k + 1;
+                        const int p_ = PRV_(k);
+                        int pk1 = -8; R pw1 = R(0), ppa = R(0), pc = R(0);                   // V_0 = 0, c_0 = 0
+                        if (p_ > 0) { pk1 = L.k1s[p_ - 1]; pw1 = L.w1s[p_ - 1]; ppa = pap[p_]; pc = L.sv[p_ - 1]; }
+                        const R pw2 = (p_ > 0) ? R(1) - pw1 : R(0), w2 = R(1) - w1[k];
+                        om = idt2 * frcp((R)(i - p_));
+                        dE = dt * (pap[i] - ppa); dc = cvr[k] - pc;
+                        const int k1k = K1_(k);
+#pragma unroll
+                        for (int r = 1; r <= F; ++r) {
+                            const R ti = (r == k1k) ? w1[k] : ((r == k1k + 1) ? w2 : R(0));
+                            const R tp = (r == pk1) ? pw1 : ((r == pk1 + 1) ? pw2 : R(0));
+                            dth[r - 1] = ti - tp;
+                        }
+                    };
+                    {
+                        R acc[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[t] = R(0);
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            if (i <= C && STA_(k) != 0) {
+                                R dth[F], om, dE, dc;
+                                pair_diffs(k, dth, om, dE, dc);
+                                int t = 0;
+#pragma unroll
+                                for (int r = 0; r < F; ++r) {
+                                    const R od = om * dth[r];
+#pragma unroll
+                                    for (int q = r; q < F; ++q) acc[t++] += od * dth[q];
+                                }
+                            }
+                        }
+                        wave_fold_sums<R, NT>(acc, L.th, lane);
+                    }
+                    {
+                        R acc[NR];
+#pragma unroll
+                        for (int t = 0; t < NR; ++t) acc[t] = R(0);
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            if (i <= C && STA_(k) != 0) {
+                                R dth[F], om, dE, dc;
+                                pair_diffs(k, dth, om, dE, dc);
+#pragma unroll
+                                for (int r = 0; r < F; ++r) { const R od = om * dth[r]; acc[r] += od * dE; acc[F + r] += od * dc; }
+                                acc[2 * F] += om * dE * dE; acc[2 * F + 1] += om * dE * dc;
+                            }
+                        }
+                        wave_fold_sums<R, NR>(acc, L.th + NT, lane);
+                    }
+                    WAVE_LDS_SYNC();
+                    // Phi(e): e < F -> +col e+1 ; e > F -> -col (e-F) + col (e-F-1) [if >= 1] ; all scaled by 1/sqrt(Qf)
+                    auto TH = [&](int r, int q) -> R {                       // Theta(r, q), 1-based, symmetric
+                        const int lo_ = min(r, q), hi_ = max(r, q);
+                        return L.th[(lo_ - 1) * F - ((lo_ - 1) * (lo_ - 2)) / 2 + (hi_ - lo_)];
+                    };
+                    for (int e = lane; e < m * m; e += 64) {
+                        const int i_ = e / m, j_ = e - i_ * m;
+                        const int ra = i_ < F ? i_ + 1 : i_ - F, rb = j_ < F ? j_ + 1 : j_ - F;     // leading column of Phi(e)
+                        const R sa = i_ < F ? R(1) : R(-1), sb = j_ < F ? R(1) : R(-1);
+                        const bool a2 = i_ > F && ra >= 2, b2 = j_ > F && rb >= 2;                   // second term: +col (r-1)
+                        R val;
+                        if (i_ == F && j_ == F) val = L.th[NT + 2 * F];
+                        else if (i_ == F || j_ == F) {
+                            const int r_ = (i_ == F) ? rb : ra; const R s1 = (i_ == F) ? sb : sa; const bool t2 = (i_ == F) ? b2 : a2;
+                            val = s1 * L.th[NT + r_ - 1];
+                            if (t2) val += L.th[NT + r_ - 2];
+                            val *= isq;
+                        } else {
+                            val = sa * sb * TH(ra, rb);
+                            if (a2) val += sb * TH(ra - 1, rb);
+                            if (b2) val += sa * TH(ra, rb - 1);
+                            if (a2 && b2) val += TH(ra - 1, rb - 1);
+                            val *= isq * isq;
+                        }
+                        L.G[e] = val;
+                    }
+                    if (lane < m) {
+                        R gv;
+                        if (lane == F) gv = L.th[NT + 2 * F + 1] - beq;
+                        else {
+                            const int ra = lane < F ? lane + 1 : lane - F;
+                            gv = (lane < F ? R(1) : R(-1)) * L.th[NT + F + ra - 1];
+                            if (lane > F && ra >= 2) gv += L.th[NT + F + ra - 2];
+                            gv *= isq;
+                        }
+                        if (lane > F) gv -= L.d1[lane - F - 1];
+                        L.hx[lane] = gv;
+                    }
+                }
+                WAVE_LDS_SYNC();
+                qz = nact;
+                Dee = stability_defect();
+                (void)solve_small(kmask);
+                const R cEw = L.cc[F];
+                // comb[r] = (cc[r-1] - ck[r] + ck[r+1]) / sqrt(Qf), r = 1..F: what a row sees through its two footstep columns
+                // (ck = the kinematic unknowns, 0 where pinned)
+                if (lane <= F + 1) L.comb[lane] = klane ? (L.cc[lane - 1] - L.cc[F + lane] + (lane + 1 <= F ? L.cc[F + lane + 1] : R(0))) * isq : R(0);
+                if (klane) muK = (kact != 0) ? (kact > 0 ? R(1) : R(-1)) * L.cc[F + lane] : R(0);
+                WAVE_LDS_SYNC();
+                R sl[RL];                                                    // s~_i = c_i - M~_i . cc on the active rows (the stability
+#pragma unroll                                                               // column dt PA_i cE is carried separately, see below)
+                for (int k = 0; k < RL; ++k) {
+                    const int i = lane * RL + k + 1;
+                    sl[k] = R(0);
+                    if (i <= C && STA_(k) != 0)
+                        sl[k] = cvr[k] - (w1[k] * L.comb[K1_(k)] + (R(1) - w1[k]) * L.comb[K1_(k) + 1]);
+                    if (i <= C) L.sv[i - 1] = sl[k];
+                }
+                WAVE_LDS_SYNC();
+                // multipliers (tridiagonal K^-1: second differences of s over the active rows) and u = dt suffix(lambda) + lambda_E a.
+                // The suffix sum telescopes: between two consecutive active rows p < j, u is the SLOPE of s over the gap (zero past the
+                // last active row) -- no scan, and a first difference instead of summed second differences.  With
+                // s = s~ - dt PA cE the slope is (s~_j - s~_p) / ((j - p) dt) - cE mean(a over the gap), so
+                //     u_i = slope~ + cE (a_i - mean a):
+                // in a run of consecutive active rows the stability multiplier (huge when the whole horizon is active) drops out
+                // exactly, as it must -- u is then fixed by the rows alone.
+#pragma unroll
+                for (int k = 0; k < RL; ++k) {
+                    const int i = lane * RL + k + 1;
+                    const int sk = STA_(k);
+                    const int pv = PRV_(k), nx = NXT_(k);
+                    const int jj = (sk != 0) ? i : nx;                           // first active row at or after this one (0: none)
+                    R r_ = R(0), uu = R(0);
+                    if (i <= C) {
+                        if (jj > 0) {
+                            const R sp = pv > 0 ? L.sv[pv - 1] : R(0);
+                            const R sj = (sk != 0) ? sl[k] : L.sv[jj - 1];
+                            const R d1 = (sj - sp) * frcp((R)(jj - pv));
+                            const R ab1 = abar(pv, jj);
+                            uu = d1 * idt + cEw * (ap[i - 1] - ab1);
+                            if (sk != 0) {
+                                r_ = d1 * idt2 - idt * cEw * ab1;
+                                if (nx > 0) r_ -= (L.sv[nx - 1] - sl[k]) * frcp((R)(nx - i)) * idt2 - idt * cEw * abar(i, nx);
+                            }
+                        } else uu = cEw * ap[i - 1];
+                    }
+                    mu[k] = sk > 0 ? r_ : -r_;
+                    u[k] = uu;
+                }
+                if (klane) fr = L.pf[lane] - L.comb[lane];
+                muE = cEw;
+                WAVE_LDS_SYNC();
+            };
+
+            // ================= block warm start (primal-dual active-set passes) =================
+            // The loop below adds one row per iteration and a nominal tick ends with 40-70 active rows.  Before it, up to
+            // c.warm_add passes put every violated ZMP row into the working set at once (and take out rows whose multiplier
+            // is not positive), each followed by ONE structured solve for the whole set: G = V'K^-1 V and g = V'K^-1 c from
+            // one sweep over the active rows (K^-1 is tridiagonal: gaps only), the (F+1)-unknown system, a tridiagonal apply
+            // and a suffix sum.  Up to c.warm_drop more passes only remove rows with negative multipliers.  What is left is a
+            // valid starting pair for Goldfarb-Idnani (minimiser on its working set, multipliers >= 0), which finishes the
+            // job and owns the kinematic rows; if the passes do not get there the solve starts cold.  Same optimum either way.
+            if (c.warm_add > 0) {
+                bool cold = false, force_add = false;
+                int peel = 1, extra = c.warm_extra, nsolve = 0;
+                // closed loop: the working set this instance ended the previous tick with, moved down by one row (the
+                // horizon advanced by one sample), is the first guess; any guess is safe, the passes validate it
+                int guess[RL];
+                bool have_guess = false;
+#pragma unroll
+                for (int k = 0; k < RL; ++k) guess[k] = 0;
+                if (hist != nullptr && hist_load) {
+                    const unsigned long long* hq = hist + (size_t)work * 8;
+                    unsigned long long any_ = 0ull;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const unsigned long long lo_ = (k < RL - 1) ? hq[k + 1] : (hq[0] >> 1);          // rows on the lower bound
+                        const unsigned long long hi_ = (k < RL - 1) ? hq[4 + k + 1] : (hq[4] >> 1);      // rows on the upper bound
+                        const int i = lane * RL + k + 1;
+                        if (i <= C) guess[k] = ((lo_ >> lane) & 1ull) ? 1 : (((hi_ >> lane) & 1ull) ? -1 : 0);
+                        any_ |= lo_ | hi_;
+                    }
+                    have_guess = any_ != 0ull;
+                }
+                for (int pass = 0; ; ++pass) {
+                    const bool adding = pass < c.warm_add || force_add;
+                    force_add = false;
+                    // ---- row values at the current point; the new working set
+                    R vv[RL];
+                    row_values(vv);
+                    // ---- rows that leave: multiplier not positive (while adding) / negative (drop-only passes).  Such a row
+                    // usually sits at the end of a run of consecutive rows on the same bound, and the run has to shrink by
+                    // more than one row ("peeling"): every pass in a row that still finds one doubles the number of rows
+                    // taken off that end (peel).  Taking off too many is harmless, they come back as violated rows.
+                    bool xdrop[RL], negr[RL], anyneg = false;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        negr[k] = STA_(k) != 0 && (adding ? !(mu[k] > R(0)) : (mu[k] < R(0)));
+                        xdrop[k] = false; anyneg = anyneg || negr[k];
+                    }
+                    const bool wave_neg = __builtin_amdgcn_ballot_w64(anyneg) != 0;
+                    if (peel > 1 && wave_neg) {
+                        const int sprev = dpp_i<0x138, 0xf>(0, STA_(RL - 1)), snext = dpp_i<0x130, 0xf>(0, STA_(0));
+                        int lst = 0, len_ = 1 << 30;                            // this lane's last run start / first run end
+                        bool isst[RL], isen[RL];
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            const int sk = STA_(k);
+                            const int sb = k > 0 ? STA_(k > 0 ? k - 1 : 0) : sprev, sa = k < RL - 1 ? STA_(k < RL - 1 ? k + 1 : 0) : snext;
+                            isst[k] = sk != 0 && sb != sk; isen[k] = sk != 0 && sa != sk;
+                            if (isst[k]) lst = i;
+                            if (isen[k]) len_ = min(len_, i);
+                            if (i <= C) L.sv[i - 1] = negr[k] ? R(1) : R(0);
+                        }
+                        int runlo[RL], runhi[RL];
+                        int run = dpp_i<0x138, 0xf>(0, wave_scan_max_i(lst));
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; if (isst[k]) run = i; runlo[k] = run; }
+                        const int rev = __shfl(len_, 63 - lane);
+                        const int ex = dpp_i<0x138, 0xf>(1 << 30, -wave_scan_max_i(-rev));
+                        run = __shfl(ex, 63 - lane);
+#pragma unroll
+                        for (int k = RL - 1; k >= 0; --k) { const int i = lane * RL + k + 1; if (isen[k]) run = i; runhi[k] = run; }
+                        WAVE_LDS_SYNC();
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            if (STA_(k) != 0 && runlo[k] >= 1 && runhi[k] <= C && runlo[k] != runhi[k]) {
+                                if (i - runlo[k] < peel && L.sv[runlo[k] - 1] != R(0)) xdrop[k] = true;
+                                if (runhi[k] - i < peel && L.sv[runhi[k] - 1] != R(0)) xdrop[k] = true;
+                            }
+                        }
+                        WAVE_LDS_SYNC();
+                    }
+                    peel = wave_neg ? min(2 * peel, 64) : 1;
+                    bool changed = false, off_bound = false;
+                    R aul = R(0);
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        if (i <= C) {
+                            const int os = STA_(k);
+                            int ns = os;
+                            const R v = vv[k];
+                            aul += ap[i - 1] * u[k];
+                            if (have_guess && pass == 0) ns = guess[k];
+                            else if (ns != 0) {
+                                // an active row must sit on its bound after the block solve; if it does not, the solve broke down
+                                const R bd = ns > 0 ? zlo : zhi;
+                                off_bound = off_bound || !(fabs(v - bd) <= (R)NM::bound_rel * (fabs(v) + fabs(bd)) + (R)NM::bound_abs);
+                                if (negr[k] || xdrop[k]) ns = 0;
+                            } else if (adding) {
+                                const R tol = (R)NM::viol_rel * (fabs(v) + fmax(fabs(zlo), fabs(zhi))) + (R)NM::viol_abs;
+                                if (v - zlo < -tol) ns = 1; else if (zhi - v < -tol) ns = -1;
+                            }
+                            changed = changed || ns != os;
+                            SET_STA_(k, ns);
+                        }
+                    }
+                    if (nsolve > 0) {
+                        const R eqr = wave_sum(aul) - beq;                         // ... and the stability row must hold
+                        if (__builtin_amdgcn_ballot_w64(off_bound) != 0 || !(fabs(eqr) <= (R)NM::eq_rel * (R(1) + fabs(beq)))) { cold = true; break; }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(changed) == 0) {               // a valid pair (and, while adding, nothing violated)
+                        if (!adding && extra > 0) { --extra; force_add = true; continue; }   // valid after drop-only passes: one more adding pass
+                        if (adding && nsolve > 0) {
+                            // every ZMP row was just evaluated at this point (none violated, active ones on their bounds, the
+                            // stability row holds, multipliers positive); with the kinematic rows inside their limits this
+                            // IS the optimum: skip the Goldfarb-Idnani search and the final re-check
+                            const R fprev = dppv<0x111, 0xf, true>(R(0), fr);
+                            bool kbad = false;
+                            if (klane && khi < R(INFINITY)) {
+                                const R vk = fr - fprev, tol = (R)NM::viol_rel * (fabs(vk) + fmax(fabs(klo), fabs(khi))) + (R)NM::viol_abs;
+                                kbad = !(vk - klo >= -tol && khi - vk >= -tol);
+                            }
+                            done_opt = __builtin_amdgcn_ballot_w64(kbad) == 0;
+                        }
+                        break;
+                    }
+                    if (nsolve >= c.warm_add + c.warm_drop + c.warm_extra * (1 + c.warm_drop)) { cold = true; break; }   // budget spent: start cold
+                    ++nsolve; ++iters;
+                    block_solve(0ull);                                           // kinematic rows stay out of the block phase
+                }
+                if (cold) {
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; SET_STA_(k, 0); mu[k] = R(0); pn[k] = 0; u[k] = (i <= C) ? t0 * ap[i - 1] : R(0); }
+                    if (klane) fr = L.pf[lane];
+                    muE = t0; qz = 0; Dee = aa;
+                    for (int e = lane; e < m * m; e += 64) L.G[e] = R(0);
+                    WAVE_LDS_SYNC();
+                }
+            }
+
+            if (!done_opt) for (;;) {
+                // ================= most violated inactive row =================
+                R cand = R(0), craw = R(0); int code = 0;
+                {
+                    R vv[RL];
+                    row_values(vv);
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        if (i <= C && STA_(k) == 0) {
+                            const R v = vv[k];
+                            const R vl = v - zlo, vh = zhi - v;
+                            const R tol = (R)NM::viol_rel * (fabs(v) + fmax(fabs(zlo), fabs(zhi))) + (R)NM::viol_abs;
+                            // 1 / |row_i|_{H^-1} (float: it only ranks candidates): |row|^2 = dt^2 i + |M_i|^2 / Qf over the footstep columns
+                            const float w1f = (float)w1[k], w2f = 1.0f - w1f;
+                            const R nr = (R)rsq_f((float)(c.dt * c.dt) * (float)i + (w2f * w2f + (K1_(k) >= 1 ? w1f * w1f : 0.0f)) * (float)iQf);
+                            if (vl < -tol && vl * nr < cand) { cand = vl * nr; craw = vl; code = 2 * i; }
+                            if (vh < -tol && vh * nr < cand) { cand = vh * nr; craw = vh; code = 2 * i + 1; }
+                        }
+                    }
+                    const R fprev = dppv<0x111, 0xf, true>(R(0), fr);             // f_{r-1} (lane 0 holds f_0 = 0)
+                    if (klane && kact == 0) {
+                        const R v = fr - fprev;
+                        const R vl = v - klo, vh = khi - v;
+                        const R tol = (R)NM::viol_rel * (fabs(v) + fmax(fabs(klo), fabs(khi))) + (R)NM::viol_abs;
+                        if (vl < -tol && vl * knrm < cand) { cand = vl * knrm; craw = vl * sq; code = 2 * (C + lane); }
+                        if (vh < -tol && vh * knrm < cand) { cand = vh * knrm; craw = vh * sq; code = 2 * (C + lane) + 1; }
+                    }
+                }
+                const R vmin = wave_min(cand);
+                if (!(vmin < R(0))) break;                                        // feasible: done
+                const int wl = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(cand == vmin));
+                const int cd = rl(code, wl);
+                R sviol = rl(craw, wl);
+                const int row = cd >> 1;
+                const R sg = (cd & 1) ? R(-1) : R(1);
+                const bool isZ = row <= C;
+                const int kr = row - C;                                           // kinematic index when !isZ
+                // ---- the new row: border row Vp (one element per lane), footstep part mt, norm, border products dX
+                int p_k1 = 0; R p_w1 = R(1), p_pa = R(0);
+                if (isZ) { p_k1 = L.k1s[row - 1]; p_w1 = L.w1s[row - 1]; p_pa = pap[row]; }
+                const R p_w2 = R(1) - p_w1;
+                const R vp = (isZ && lane < m) ? border_elem<R, F>(lane, p_k1, p_w1, p_pa, dt, isq) : R(0);
+                R mt_e = R(0), dx_e = R(0);                                       // lane e: mt[e] (e < F), dX[e] (e >= F)
+                if (isZ) { if (lane < F) mt_e = sg * vp; else if (lane < m) dx_e = sg * vp; }
+                else {
+                    if (lane < F) { const int r = lane + 1; mt_e = (r == kr) ? -sg : ((r == kr - 1) ? sg : R(0)); }      // -sg kvec
+                    else if (lane > F && lane < m) { const int r = lane - F; dx_e = sg * ((r == kr) ? (kr >= 2 ? R(2) : R(1)) : ((r == kr - 1 || r == kr + 1) ? R(-1) : R(0))); }
+                }
+                if (lane < m) { L.vp[lane] = vp; L.mt[lane] = mt_e; }
+                const R npn = isZ ? (dt * dt * (R)row + ((p_k1 >= 1 ? p_w1 * p_w1 : R(0)) + p_w2 * p_w2) * iQf) : (kr >= 2 ? R(2) : R(1));
+                R mu_p = R(0);
+                bool failed = false, fresh = true;                                // fresh: sviol still valid from the search
+                // ================= steps until the row enters (Goldfarb-Idnani) =================
+                for (;;) {
+                    if (++iters > c.max_iter) { status |= ISMPC_A_ST_ITER_LIMIT; failed = true; break; }
+                    // ---- violation of the row at the current point (after a partial step)
+                    if (!fresh) {
+                        if (isZ) {
+                            R vv[RL];
+                            row_values(vv);
+                            const R v = at_row<R, RL>(vv, row);
+                            sviol = sg > R(0) ? v - zlo : zhi - v;
+                        } else {
+                            const R fprev = dppv<0x111, 0xf, true>(R(0), fr);
+                            const R vk = sg > R(0) ? (fr - fprev) - klo : khi - (fr - fprev);
+                            sviol = sq * rl(vk, kr);
+                        }
+                    }
+                    fresh = false;
+                    // ---- neighbours (na < row < nb) of a new ZMP row among the active ones; V there
+                    int na = 0, nb = 0; R th = R(0), va = R(0), vb = R(0), vint = R(0);
+                    if (isZ && qz > 0) {
+                        const int pnr = at_row<int, RL>(pn, row);                  // prv / nxt are kept for every row, active or not
+                        na = pnr & 0xffff; nb = (int)((unsigned)pnr >> 16);
+                        if (na > 0 && lane < m) va = border_elem<R, F>(lane, L.k1s[na - 1], L.w1s[na - 1], pap[na], dt, isq);
+                        if (nb > 0 && lane < m) vb = border_elem<R, F>(lane, L.k1s[nb - 1], L.w1s[nb - 1], pap[nb], dt, isq);
+                        if (nb == 0) { vint = va; th = R(0); }
+                        else if (na == 0) { th = (R)row * frcp((R)nb); vint = th * vb; }
+                        else { th = (R)(row - na) * frcp((R)(nb - na)); vint = va + th * (vb - va); }
+                    }
+                    // ---- small quasi-definite system  [[I+G11, G1x],[Gx1, Gxx - Sxx]] cc = [h1 ; hx - dX]
+                    // unknown order: 0..F-1 footstep columns, F = stability row, F+1..2F = Khat_1..F (inactive: pinned to 0)
+                    if (lane < m) {
+                        R h_e = sg * vint;
+#pragma unroll
+                        for (int r = 0; r < F; ++r) h_e += L.G[lane * m + r] * L.mt[r];
+                        L.hx[lane] = h_e - dx_e;
+                    }
+                    WAVE_LDS_SYNC();
+                    const unsigned long long kmask = __builtin_amdgcn_ballot_w64(klane && kact != 0);   // bit r: Khat_r active
+                    Dee = stability_defect();
+                    const R cc_e = solve_small(kmask);
+                    const R cE = L.cc[F];
+                    // ---- y = coefficients on the V columns (delta_Z - V cc = sg dt^2 k_i + V y); rows see the footstep
+                    // columns through comb[k1], comb[k1+1]:  comb[r] = (yM_r - yK_r + yK_{r+1}) / sqrt(Qf)
+                    if (lane <= F + 1) {
+                        R cb = R(0);
+                        if (klane) {
+                            const int r = lane;
+                            const R yM = L.mt[r - 1] - L.cc[r - 1], yK = -L.cc[F + r], yKn = (r + 1 <= F) ? -L.cc[F + r + 1] : R(0);
+                            cb = (yM - yK + yKn) * isq;
+                        }
+                        L.comb[lane] = cb;
+                    }
+                    WAVE_LDS_SYNC();
+                    R svl[RL];
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        svl[k] = (i <= C) ? (w1[k] * L.comb[K1_(k)] + (R(1) - w1[k]) * L.comb[K1_(k) + 1]) : R(0);   // without - dt PA_i cE (split off, as in block_solve)
+                        if (i <= C) L.sv[i - 1] = svl[k];
+                    }
+                    WAVE_LDS_SYNC();
+                    // ---- rho per active ZMP row (tridiagonal K^-1) + interpolation weights; d.r ; dual step length
+                    R rho[RL], ddl = R(0), tcand = R(INFINITY); int tcode = 0;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        const int sk = STA_(k);
+                        rho[k] = R(0);
+                        if (i <= C && sk != 0) {
+                            const int pv = PRV_(k), nx = NXT_(k);
+                            const R sp = pv > 0 ? L.sv[pv - 1] : R(0);
+                            R r_ = (svl[k] - sp) * frcp((R)(i - pv)) * idt2 - idt * cE * abar(pv, i);
+                            if (nx > 0) r_ -= (L.sv[nx - 1] - svl[k]) * frcp((R)(nx - i)) * idt2 - idt * cE * abar(i, nx);
+                            if (isZ) {
+                                if (i == na) r_ += (nb == 0) ? sg : sg * (R(1) - th);
+                                if (i == nb) r_ += sg * th;
+                            }
+                            rho[k] = r_;
+                            const R w2k = R(1) - w1[k];
+                            const int b1 = K1_(k);
+                            R dj;                                                  // sg <row+, Z_i>
+                            if (isZ) {
+                                R mm = R(0);                                       // M_p . M_i
+                                const int a1 = p_k1;
+                                if (a1 >= 1) { if (a1 == b1) mm += p_w1 * w1[k]; else if (a1 == b1 + 1) mm += p_w1 * w2k; }
+                                { const int cx = a1 + 1; if (cx == b1 && b1 >= 1) mm += p_w2 * w1[k]; else if (cx == b1 + 1) mm += p_w2 * w2k; }
+                                dj = sg * (dt * dt * (R)min(row, i) + mm * iQf);
+                            } else {
+                                R mk = R(0);                                       // M_i . kvec_kr
+                                if (b1 == kr) mk += w1[k];
+                                if (b1 + 1 == kr) mk += w2k;
+                                if (kr - 1 >= 1) { if (b1 == kr - 1) mk -= w1[k]; if (b1 + 1 == kr - 1) mk -= w2k; }
+                                dj = sg * (-mk) * isq;
+                            }
+                            ddl += dj * r_;
+                            const R rs = (sk > 0 ? R(1) : R(-1)) * r_;
+                            if (rs > R(0)) { const R tt = mu[k] * frcp(rs); if (tt < tcand) { tcand = tt; tcode = i; } }
+                        }
+                    }
+                    if (lane >= F && lane < m) ddl += dx_e * cc_e;                 // border part of d.r
+                    const R cK = (klane) ? L.cc[F + lane] : R(0);                  // lane r: unsigned cc of Khat_r
+                    if (klane && kact != 0) {
+                        const R rs = (kact > 0 ? R(1) : R(-1)) * cK;
+                        if (rs > R(0)) { const R tt = muK * frcp(rs); if (tt < tcand) { tcand = tt; tcode = C + lane; } }
+                    }
+                    const R gamma = npn - wave_sum(ddl);
+                    const R t1 = wave_min(tcand);
+                    int lrow = 0;
+                    if (t1 < R(INFINITY)) lrow = rl(tcode, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(tcand == t1)));
+                    const R t2 = (gamma > (R)NM::gamma_rel * npn) ? -sviol / gamma : R(INFINITY);
+                    const R t = fmin(t1, t2);
+                    if (!(t < R(INFINITY))) { status |= (axis == 0 ? ISMPC_A_ST_X_INFEASIBLE : ISMPC_A_ST_Y_INFEASIBLE); failed = true; break; }
+                    // ---- primal step: z_u = suffix sum of (-dt rho, + sg dt at the new row) - r_E a ; z_f from cc
+                    if (t2 < R(INFINITY)) {
+                        // z_u(i) = dt (sg [i <= row] - sum over active i' >= i of rho_i') - r_E a: the sum of the tridiagonal part
+                        // telescopes to the slope of svl between the two active rows around i, the interpolation weights of the
+                        // new row (1 - th at na, th at nb) and its own impulse are step functions -- no scan
+                        const R wA = (isZ && na > 0) ? (nb == 0 ? R(1) : R(1) - th) : R(0), wB = (isZ && nb > 0) ? th : R(0);
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            if (i <= C) {
+                                const int sk = STA_(k);
+                                const int pv = PRV_(k), nx = NXT_(k);
+                                const int jj = (sk != 0) ? i : nx;
+                                R zu = -cE * ap[i - 1];
+                                if (jj > 0) {
+                                    const R sp = pv > 0 ? L.sv[pv - 1] : R(0);
+                                    const R sj = (sk != 0) ? svl[k] : L.sv[jj - 1];
+                                    zu = -(sj - sp) * frcp((R)(jj - pv)) * idt - cE * (ap[i - 1] - abar(pv, jj));   // the stability multiplier
+                                }                                                                              // drops out of active runs
+                                if (isZ) {
+                                    const R stepf = (i <= row ? R(1) : R(0)) - (i <= na ? wA : R(0)) - (i <= nb ? wB : R(0));
+                                    zu += sg * dt * stepf;
+                                }
+                                u[k] += t * zu;
+                            }
+                        }
+                        if (klane) {
+                            // z_f[r] = ( n+_f[r] + sqrt(Qf) c1[r] - sqrt(Qf) (cK[r] - cK[r+1]) ) / Qf
+                            const int r = lane;
+                            R nf = isZ ? -sg * L.vp[r - 1] * sq : ((r == kr) ? sg * sq : ((r == kr - 1) ? -sg * sq : R(0)));
+                            nf += sq * L.cc[r - 1];
+                            nf -= sq * cK;
+                            if (r + 1 <= F) nf += sq * L.cc[F + r + 1];
+                            fr += t * nf * iQf;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) { const int sk = STA_(k); if (sk != 0) mu[k] -= t * (sk > 0 ? R(1) : R(-1)) * rho[k]; }
+                    if (klane && kact != 0) muK -= t * (kact > 0 ? R(1) : R(-1)) * cK;
+                    muE -= t * cE;
+                    mu_p += t;
+                    if (t2 < R(INFINITY) && t == t2) {
+                        // ============ the row enters ============
+                        if (isZ) {
+                            if (lane < m) { L.d1[lane] = vp - va; L.d2[lane] = (nb > 0 ? vb : R(0)) - vp; L.d0[lane] = (nb > 0 ? vb : R(0)) - va; }
+                            WAVE_LDS_SYNC();
+                            const R g1 = idt2 * frcp((R)(row - na)), g2 = nb > 0 ? idt2 * frcp((R)(nb - row)) : R(0), g0 = nb > 0 ? idt2 * frcp((R)(nb - na)) : R(0);
+                            for (int e = lane; e < m * m; e += 64) {
+                                const int i = e / m, jj = e - i * m;
+                                L.G[e] += g1 * L.d1[i] * L.d1[jj] + g2 * L.d2[i] * L.d2[jj] - g0 * L.d0[i] * L.d0[jj];
+                            }
+                            WAVE_LDS_SYNC();
+#pragma unroll
+                            for (int k = 0; k < RL; ++k) {
+                                const int i = lane * RL + k + 1;
+                                if (i == row) { SET_STA_(k, sg > R(0) ? 1 : -1); mu[k] = mu_p; }
+                                if (i >= na && i < row) SET_NXT_(k, row);          // rows that now see `row` as their next / previous active row
+                                if (i > row && (nb == 0 || i <= nb)) SET_PRV_(k, row);
+                            }
+                            ++qz;
+                        } else {
+                            if (lane == kr) { kact = sg > R(0) ? 1 : -1; muK = mu_p; }
+                            ++qk;
+                        }
+                        break;
+                    }
+                    // ============ partial step: working-set row lrow leaves ============
+                    if (lrow <= C) {
+                        const int pnl = at_row<int, RL>(pn, lrow);
+                        const int pa_ = pnl & 0xffff, pb_ = (int)((unsigned)pnl >> 16);
+                        R vl_ = R(0), wa_ = R(0), wb_ = R(0);
+                        if (lane < m) {
+                            vl_ = border_elem<R, F>(lane, L.k1s[lrow - 1], L.w1s[lrow - 1], pap[lrow], dt, isq);
+                            if (pa_ > 0) wa_ = border_elem<R, F>(lane, L.k1s[pa_ - 1], L.w1s[pa_ - 1], pap[pa_], dt, isq);
+                            if (pb_ > 0) wb_ = border_elem<R, F>(lane, L.k1s[pb_ - 1], L.w1s[pb_ - 1], pap[pb_], dt, isq);
+                            L.d1[lane] = vl_ - wa_; L.d2[lane] = (pb_ > 0 ? wb_ : R(0)) - vl_; L.d0[lane] = (pb_ > 0 ? wb_ : R(0)) - wa_;
+                        }
+                        WAVE_LDS_SYNC();
+                        const R g1 = idt2 * frcp((R)(lrow - pa_)), g2 = pb_ > 0 ? idt2 * frcp((R)(pb_ - lrow)) : R(0), g0 = pb_ > 0 ? idt2 * frcp((R)(pb_ - pa_)) : R(0);
+                        for (int e = lane; e < m * m; e += 64) {
+                            const int i = e / m, jj = e - i * m;
+                            L.G[e] -= g1 * L.d1[i] * L.d1[jj] + g2 * L.d2[i] * L.d2[jj] - g0 * L.d0[i] * L.d0[jj];
+                        }
+                        WAVE_LDS_SYNC();
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            if (i == lrow) { SET_STA_(k, 0); mu[k] = R(0); }
+                            if (i >= pa_ && i < lrow) SET_NXT_(k, pb_);
+                            if (i > lrow && (pb_ == 0 || i <= pb_)) SET_PRV_(k, pa_);
+                        }
+                        --qz;
+                    } else {
+                        if (lane == lrow - C) { kact = 0; muK = R(0); }
+                        --qk;
+                    }
+                }
+                if (failed) break;
+            }
+            // ---- every row, active or not, the kinematic rows and the stability row are checked once more at the point that
+            // is about to be returned: a working set that pins (nearly) every variable can wear the incremental solves down
+            // without any inactive row showing it.  One block solve of the final working set (kinematic rows included)
+            // polishes such a point; if it still fails, the QP is reported infeasible (the reference's quadprog returns no
+            // solution on infeasible QPs).
+            if (status == 0 && !done_opt) {
+                auto off_point = [&]() __attribute__((always_inline)) -> bool {
+                    R vv[RL], aul = R(0);
+                    row_values(vv);
+                    bool bad = false;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int i = lane * RL + k + 1;
+                        if (i <= C) {
+                            const R v = vv[k];
+                            const R tol = (R)NM::final_rel * (fabs(v) + fmax(fabs(zlo), fabs(zhi))) + (R)NM::final_abs;
+                            bad = bad || !(v - zlo >= -tol && zhi - v >= -tol);
+                            aul += ap[i - 1] * u[k];
+                        }
+                    }
+                    const R fprev = dppv<0x111, 0xf, true>(R(0), fr);
+                    if (klane && khi < R(INFINITY)) {
+                        const R v = fr - fprev, tol = (R)NM::final_rel * (fabs(v) + fmax(fabs(klo), fabs(khi))) + (R)NM::final_abs;
+                        bad = bad || !(v - klo >= -tol && khi - v >= -tol);
+                    }
+                    const R eqr = wave_sum(aul) - beq;
+                    WAVE_LDS_SYNC();
+                    return __builtin_amdgcn_ballot_w64(bad) != 0 || !(fabs(eqr) <= (R)NM::final_rel * (R(1) + fabs(beq)));
+                };
+                bool bad = off_point();
+                if (bad && c.warm_add > 0) {
+                    ++iters;
+                    block_solve(__builtin_amdgcn_ballot_w64(klane && kact != 0));
+                    R mmax = fabs(muK);
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) mmax = fmax(mmax, fabs(mu[k]));
+                    const R mtol = (R)NM::mult_rel * (R(1) - wave_min(-mmax));
+                    bool negm = klane && kact != 0 && muK < -mtol;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) negm = negm || (STA_(k) != 0 && mu[k] < -mtol);
+                    bad = __builtin_amdgcn_ballot_w64(negm) != 0 || off_point();
+                }
+                if (bad) status |= (axis == 0 ? ISMPC_A_ST_X_INFEASIBLE : ISMPC_A_ST_Y_INFEASIBLE) | ISMPC_A_ST_UNVERIFIED;
+            }
+        }
+
+        if (hist != nullptr) {
+            unsigned long long* hq = hist + (size_t)work * 8;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) {
+                const unsigned long long lo_ = __builtin_amdgcn_ballot_w64(status == 0 && STA_(k) > 0), hi_ = __builtin_amdgcn_ballot_w64(status == 0 && STA_(k) < 0);
+                if (lane == 0) { hq[k] = lo_; hq[4 + k] = hi_; }
+            }
+        }
+        // ---- LIP update (:297-322), footstep bookkeeping (:522-556), outputs: fp64 whatever the precision of the solve
+        const bool ok = (status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) == 0;
+        const double u0 = ok ? (double)rl(u[0], 0) : 0.0;
+        const double f0 = ok ? cur + (double)rl(fr, 1) : cur;
+        if (lane == 0) {
+            const double p0 = pos, v0 = vel, z0 = zmp;
+            double np_, nv_, nz_;
+            if (PI) {                                                            // A_upd, B_upd for this instance's eta (:67-71)
+                const double ch = cosh(eta * c.dt), sh = sinh(eta * c.dt);
+                np_ = (ch * p0 + (sh / eta) * v0 + (1 - ch) * z0) + (c.dt - sh / eta) * u0;
+                nv_ = ((eta * sh) * p0 + ch * v0 + (-eta * sh) * z0) + (1 - ch) * u0;
+                nz_ = (0.0 * p0 + 0.0 * v0 + 1.0 * z0) + c.dt * u0;
+            } else {
+                np_ = (c.Au[0] * p0 + c.Au[1] * v0 + c.Au[2] * z0) + c.Bu[0] * u0;
+                nv_ = (c.Au[3] * p0 + c.Au[4] * v0 + c.Au[5] * z0) + c.Bu[1] * u0;
+                nz_ = (c.Au[6] * p0 + c.Au[7] * v0 + c.Au[8] * z0) + c.Bu[2] * u0;
+            }
+            ismpc_a_state* so = state + inst;
+            const bool stepped = ok && (j + 1 >= step_ * fc);
+            if (ok) {
+                if (axis == 0) { so->x = np_; so->xd = nv_; so->xz = nz_; } else { so->y = np_; so->yd = nv_; so->yz = nz_; }
+                if (stepped) {
+                    const double noff = f0 - fs[fc];
+                    if (axis == 0) { so->cur_x = f0; so->off_x = noff; } else { so->cur_y = f0; so->off_y = noff; }
+                }
+                if (axis == 0) { so->j = j + 1; if (stepped) { so->fc = fc + 1; so->rebuilt = 1; } }
+            }
+            if (out) {
+                ismpc_a_out* o = out + inst;
+                const int q = 1 + qz + qk;
+                o->com_before[axis] = pos; o->vel_after[axis] = ok ? nv_ : vel; o->u0[axis] = u0; o->f0[axis] = f0;
+                if (axis == 0) { o->iters_x = iters; atomicOr(&o->status, status); atomicOr(&o->active, q & 0xffff); }
+                else { o->iters_y = iters; atomicOr(&o->status, status); atomicOr(&o->active, (q & 0xffff) << 16); }
+            }
+        }
+        WAVE_LDS_SYNC();
+#undef K1_
+#undef STA_
+#undef SET_STA_
+#undef PRV_
+#undef NXT_
+#undef SET_PRV_
+#undef SET_NXT_
+    }
+}
+
+// ---- launch: persistent grid = exactly the workgroups that are resident at once (registers / LDS decide how many per CU)
+template <typename R, int RL, int F, bool PI>
+inline int launch_one(const WaveLaunch& L, hipError_t* err)
+{
+    auto kern = ismpc_a_tick_wave<R, RL, F, PI>;
+    int& occ = L.occ_cache[(sizeof(R) == 4 ? 2 : 0) + (PI ? 1 : 0)];
+    if (occ == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WG, 0) != hipSuccess || nb < 1) nb = 1;
+        occ = nb;
+    }
+    const int grid = std::min((2 * L.batch + 3) / 4, L.cus * occ);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), 0, L.stream, L.c_dev, L.prev, L.state, L.inst, L.push, L.out, L.batch, L.work_counter, L.hist, L.hist_load);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { if (err) *err = e; return -2; }
+    return 0;
+}
+template <typename R, int RL, int F>
+inline int launch_pi(const WaveLaunch& L, hipError_t* err) { return L.inst ? launch_one<R, RL, F, true>(L, err) : launch_one<R, RL, F, false>(L, err); }
+template <typename R, int RL>
+inline int launch_f(const WaveLaunch& L, hipError_t* err)
+{
+    switch (L.F) {
+        case 3: return launch_pi<R, RL, 3>(L, err);
+        case 4: return launch_pi<R, RL, 4>(L, err);
+        case 5: return launch_pi<R, RL, 5>(L, err);
+        case 6: return launch_pi<R, RL, 6>(L, err);
+        default: return -1;
+    }
+}
+template <int RL>
+inline int launch_wave(const WaveLaunch& L, hipError_t* err) { return L.precision == 1 ? launch_f<float, RL>(L, err) : launch_f<double, RL>(L, err); }
+
+}  // namespace ismpc_a

@@ -1,0 +1,4 @@
+// Formulation A wavefront-per-QP kernels, 3 ZMP rows per lane (C <= 192): one translation unit per rows-per-lane value so
+// that the instantiations (2 precisions x 4 footstep counts x per-instance yes/no) compile side by side.
+#include "ismpc_a_wave.hpp"
+namespace ismpc_a { int launch_wave_rl3(const WaveLaunch& L, hipError_t* err) { return launch_wave<3>(L, err); } }

@@ -37,7 +37,8 @@ EXPORTS_A = ["ismpc_a_params_default", "ismpc_a_gait_default", "ismpc_a_plan", "
              "ismpc_a_initial_state", "ismpc_a_tick_batch_device", "ismpc_a_rollout_device", "ismpc_a_last_error",
              "ismpc_a_feet_rows", "ismpc_a_feet_init_device", "ismpc_a_tick_feet_batch_device",
              "ismpc_a_rollout_feet_device", "ismpc_a_foot_trajectories", "ismpc_a_write_trajectory_txt",
-             "ismpc_a_add_plan", "ismpc_a_tick_batch_inst_device", "ismpc_a_rollout_inst_device", "ismpc_a_set_warm_history", "ismpc_a_reserve"]
+             "ismpc_a_add_plan", "ismpc_a_tick_batch_inst_device", "ismpc_a_rollout_inst_device", "ismpc_a_set_warm_history", "ismpc_a_reserve", "ismpc_a_set_precision"]
+HAVE_F32 = True        # the QP solve also exists in fp32 (GaitGenerator(..., precision="f32"))
 FEET_PAD = 8
 
 _bound = False
@@ -68,6 +69,7 @@ def _l():
         lib.ismpc_a_tick_batch_inst_device.argtypes = [vp, ci, vp, vp, vp, vp, vp]; lib.ismpc_a_tick_batch_inst_device.restype = ci
         lib.ismpc_a_rollout_inst_device.argtypes = [vp, ci, vp, vp, ci, vp, vp]; lib.ismpc_a_rollout_inst_device.restype = ci
         lib.ismpc_a_reserve.argtypes = [vp, ci]; lib.ismpc_a_reserve.restype = ci
+        lib.ismpc_a_set_precision.argtypes = [vp, ci]; lib.ismpc_a_set_precision.restype = ci
         _bound = True
     return lib
 
@@ -125,7 +127,12 @@ class GaitGenerator:
     """The MATLAB loop `for j = 1:sim_duration` (quad_walk_no_plots.m:127 / quad_as_bip_no_plots.m:116),
     batched: every instance carries its own (state, footstep counter, plan shift)."""
 
-    def __init__(self, params, center, device=0):
+    def __init__(self, params, center, device=0, precision="f64"):
+        """precision: arithmetic type of the QP solve, "f64" (default) or "f32" (ismpc_a_set_precision); the state, the
+        right-hand sides of the QP and the LIP update are fp64 either way."""
+        if precision not in ("f64", "f32"):
+            raise ValueError("precision must be 'f64' or 'f32'")
+        self.precision = precision
         self.params = params
         self.center = np.ascontiguousarray(center, dtype=np.float64)
         h = C.c_void_p()
@@ -133,6 +140,9 @@ class GaitGenerator:
         if rc != 0:
             raise IsmpcAError(f"ismpc_a_create: {rc}: {_l().ismpc_a_last_error().decode()}")
         self._h = h
+        if _l().ismpc_a_set_precision(self._h, 1 if precision == "f32" else 0) != 0:
+            msg = _l().ismpc_a_last_error().decode(); self.close()
+            raise IsmpcAError(msg)
 
     def close(self):
         if getattr(self, "_h", None) and _l is not None:

@@ -11,7 +11,7 @@ md = None
 if "--md" in args:
     md = args[args.index("--md") + 1]; del args[args.index("--md"):args.index("--md") + 2]
 rows = []
-for src in ("ismpc_hip.hip", "ismpc_a_hip.hip"):
+for src in ("ismpc_hip.hip", "ismpc_a_hip.hip", "ismpc_a_wave_rl2.hip", "ismpc_a_wave_rl3.hip", "ismpc_a_wave_rl4.hip"):
     with tempfile.TemporaryDirectory() as td:
         r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
                             "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", os.path.join(td, "x.o")]
@@ -26,7 +26,7 @@ for src in ("ismpc_hip.hip", "ismpc_a_hip.hip"):
         k, v = m.group(1), m.group(2)
         if k == "Function Name":
             name = subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip()
-            name = re.sub(r"\(anonymous namespace\)::", "", name); name = re.sub(r"\(.*$", "", name); name = re.sub(r"^void ", "", name)
+            name = re.sub(r"\(anonymous namespace\)::|ismpc_a::", "", name); name = re.sub(r"\(.*$", "", name); name = re.sub(r"^void ", "", name)
             cur = {"kernel": name, "file": src}; rows.append(cur)
         elif cur is not None:
             cur[k.split(" [")[0]] = int(v)
