@@ -232,7 +232,22 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 
 // Residency target (wavefronts per SIMD = workgroups per CU, 256 threads each): fp64 3 for two rows per lane and 2 beyond
 // (measured round 1: the 128-register budget of 4 per CU spills), fp32 4 / 3.
-template <typename R, int RL> constexpr int wave_min_blocks() { return sizeof(R) == 4 ? (RL <= 2 ? 4 : 3) : (RL <= 2 ? 3 : 2); }
+#ifndef ISMPC_A_OCC_F32_RL2      // tuning knobs (scripts/occ_sweep.sh builds variants)
+#define ISMPC_A_OCC_F32_RL2 4
+#endif
+#ifndef ISMPC_A_OCC_F32_RL34
+#define ISMPC_A_OCC_F32_RL34 3
+#endif
+#ifndef ISMPC_A_OCC_F64_RL2
+#define ISMPC_A_OCC_F64_RL2 3
+#endif
+#ifndef ISMPC_A_OCC_F64_RL34
+#define ISMPC_A_OCC_F64_RL34 2
+#endif
+template <typename R, int RL> constexpr int wave_min_blocks()
+{
+    return sizeof(R) == 4 ? (RL <= 2 ? ISMPC_A_OCC_F32_RL2 : ISMPC_A_OCC_F32_RL34) : (RL <= 2 ? ISMPC_A_OCC_F64_RL2 : ISMPC_A_OCC_F64_RL34);
+}
 
 // RL = ZMP rows per lane (C <= 64 RL), F = footsteps in the horizon (m = 2F+1 border columns).
 // PI: per-instance gait parameters (ismpc_a_inst): height, Qf, step, ds, F <= the template F, base plan.
@@ -250,6 +265,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     __shared__ R a_pi[PI ? WG / 64 : 1][PI ? WG : 1], pa_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1];   // ... or one per wavefront
     // the same prefix sums and those of a^2 in fp64, whatever the precision of the solve: the two places where the stability row
     // is (nearly) in the span of the active ZMP rows are evaluated from them without cancellation (see gap_terms below)
+    __shared__ R rinv[WG + 1];                              // 1 / g for the index gaps g = 1 .. C between active rows (a read instead of a division)
     __shared__ double pad_s[PI ? 1 : WG + 1], pa2d_s[PI ? 1 : WG + 1];
     __shared__ double pad_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1], pa2d_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1];
     const int lane = threadIdx.x & 63;
@@ -258,10 +274,12 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     const int C = c.C, P = c.P;
     const R dt = (R)c.dt, idt = (R)(1.0 / c.dt), idt2 = (R)(1.0 / (c.dt * c.dt));
     const bool klane = lane >= 1 && lane <= F;            // lane r owns kinematic row r (and f_r)
+    for (int k = threadIdx.x; k <= WG; k += WG) rinv[k] = k > 0 ? (R)(1.0 / (double)k) : R(0);
+    if (threadIdx.x == 0) rinv[WG] = (R)(1.0 / (double)WG);
     if (!PI) {
         for (int k = threadIdx.x; k <= C; k += WG) { pa_s[k] = (R)c.PA[k]; pad_s[k] = c.PA[k]; pa2d_s[k] = c.PA2[k]; if (k < C) a_s[k] = (R)c.a[k]; }
-        __syncthreads();
     }
+    __syncthreads();
     const R* ap = PI ? a_pi[PI ? wv : 0] : a_s;
     const R* pap = PI ? pa_pi[PI ? wv : 0] : pa_s;
     const double* pad = PI ? pad_pi[PI ? wv : 0] : pad_s;
@@ -310,10 +328,13 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             const double k1c = (1 / eta) * (1 - lam) / (1 - pow(lam, (double)C)), k2c = c.dt * 1.0 * exp(-eta * c.dt * C);
             double* padw = pad_pi[PI ? wv : 0]; double* pa2dw = pa2d_pi[PI ? wv : 0];
             double av[RL], cum[RL], cum2[RL], loc = 0.0, sqs = 0.0;
+            // a_i = k1c lambda^i - k2c: one exp per lane (its first row), then powers of lambda
+            double lp = exp(-eta * c.dt * (lane * RL));
 #pragma unroll
             for (int k = 0; k < RL; ++k) {
                 const int i0 = lane * RL + k;
-                av[k] = (i0 < C) ? k1c * exp(-eta * c.dt * i0) - k2c : 0.0;
+                av[k] = (i0 < C) ? k1c * lp - k2c : 0.0;
+                lp *= lam;
                 loc += av[k]; cum[k] = loc; sqs += av[k] * av[k]; cum2[k] = sqs;
             }
             const double base = wave_scan_up(loc) - loc, base2 = wave_scan_up(sqs) - sqs;
@@ -361,9 +382,13 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         double tl = 0.0;
         if (!(status & ISMPC_A_ST_BAD_INDEX)) {
             if (PI) {
-                const double om = 1 - exp(-eta * c.dt);
-                for (int i = C + 1 + lane; i <= P; i += 64)
-                    tl += exp(-eta * c.dt * i) * om * ((cl_closed(fs, step_, ds_, st.rebuilt != 0, j + i - 1) + cloff) - cur);
+                const double om = 1 - exp(-eta * c.dt), l64 = exp(-eta * c.dt * 64);
+                double wi = exp(-eta * c.dt * (C + 1 + lane)) * om;
+#pragma nounroll
+                for (int i = C + 1 + lane; i <= P; i += 64) {
+                    tl += wi * ((cl_closed(fs, step_, ds_, st.rebuilt != 0, j + i - 1) + cloff) - cur);
+                    wi *= l64;
+                }
             } else
                 for (int i = C + 1 + lane; i <= P; i += 64) tl += c.wtail[i - (C + 1)] * ((cl[j + i - 1] + cloff) - cur);
         }
@@ -415,7 +440,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             // but for the footstep coupling, which is 1/Qf small): formed as ONE sum of per-gap terms
             //     [sum a^2 - (sum a)^2 / (i - p)]  +  (sum of a^2 past the last active row),
             // each from the fp64 prefix sums, it is exact where it matters (a gap of one row contributes exactly 0).
-            auto stability_defect = [&]() __attribute__((always_inline)) -> R {
+            auto stability_defect = [&]() __attribute__((always_inline)) -> double {
                 double dl = 0.0;
 #pragma unroll
                 for (int k = 0; k < RL; ++k) {
@@ -428,10 +453,17 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     }
                 }
                 if (qz == 0 && lane == 0) dl = pa2d[C];
-                return (R)wave_sum(dl);
+                return wave_sum(dl);
             };
+            // the same terms one at a time, for the rows that enter / leave in the Goldfarb-Idnani loop (wave-uniform, fp64)
+            auto gap_term = [&](int p_, int i_) __attribute__((always_inline)) -> double {
+                const double sa = pad[i_] - pad[p_];
+                return (pa2d[i_] - pa2d[p_]) - sa * sa * frcp((double)(i_ - p_));
+            };
+            auto tail_term = [&](int p_) __attribute__((always_inline)) -> double { return pa2d[C] - pa2d[p_]; };
+            double Dd = pa2d[C];
             // mean of a over the samples p+1 .. j (consecutive active rows p < j), from the fp64 prefix sums
-            auto abar = [&](int p_, int j_) __attribute__((always_inline)) -> R { return (R)(pad[j_] - pad[p_]) * frcp((R)(j_ - p_)); };
+            auto abar = [&](int p_, int j_) __attribute__((always_inline)) -> R { return (R)(pad[j_] - pad[p_]) * rinv[j_ - p_]; };
             R Dee = aa;
 
             // ---- small quasi-definite system  [[I+G11, G1x],[Gx1, Gxx - Sxx]] cc = rhs (L.hx), G in L.G; unknown order:
@@ -521,7 +553,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         int pk1 = -8; R pw1 = R(0), ppa = R(0), pc = R(0);                   // V_0 = 0, c_0 = 0
                         if (p_ > 0) { pk1 = L.k1s[p_ - 1]; pw1 = L.w1s[p_ - 1]; ppa = pap[p_]; pc = L.sv[p_ - 1]; }
                         const R pw2 = (p_ > 0) ? R(1) - pw1 : R(0), w2 = R(1) - w1[k];
-                        om = idt2 * frcp((R)(i - p_));
+                        om = idt2 * rinv[i - p_];
                         dE = dt * (pap[i] - ppa); dc = cvr[k] - pc;
                         const int k1k = K1_(k);
 #pragma unroll
@@ -611,7 +643,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 }
                 WAVE_LDS_SYNC();
                 qz = nact;
-                Dee = stability_defect();
+                Dd = stability_defect(); Dee = (R)Dd;
                 (void)solve_small(kmask);
                 const R cEw = L.cc[F];
                 // comb[r] = (cc[r-1] - ck[r] + ck[r+1]) / sqrt(Qf), r = 1..F: what a row sees through its two footstep columns
@@ -647,12 +679,12 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         if (jj > 0) {
                             const R sp = pv > 0 ? L.sv[pv - 1] : R(0);
                             const R sj = (sk != 0) ? sl[k] : L.sv[jj - 1];
-                            const R d1 = (sj - sp) * frcp((R)(jj - pv));
+                            const R d1 = (sj - sp) * rinv[jj - pv];
                             const R ab1 = abar(pv, jj);
                             uu = d1 * idt + cEw * (ap[i - 1] - ab1);
                             if (sk != 0) {
                                 r_ = d1 * idt2 - idt * cEw * ab1;
-                                if (nx > 0) r_ -= (L.sv[nx - 1] - sl[k]) * frcp((R)(nx - i)) * idt2 - idt * cEw * abar(i, nx);
+                                if (nx > 0) r_ -= (L.sv[nx - 1] - sl[k]) * rinv[nx - i] * idt2 - idt * cEw * abar(i, nx);
                             }
                         } else uu = cEw * ap[i - 1];
                     }
@@ -798,7 +830,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #pragma unroll
                     for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; SET_STA_(k, 0); mu[k] = R(0); pn[k] = 0; u[k] = (i <= C) ? t0 * ap[i - 1] : R(0); }
                     if (klane) fr = L.pf[lane];
-                    muE = t0; qz = 0; Dee = aa;
+                    muE = t0; qz = 0; Dd = pa2d[C]; Dee = (R)Dd;
                     for (int e = lane; e < m * m; e += 64) L.G[e] = R(0);
                     WAVE_LDS_SYNC();
                 }
@@ -882,8 +914,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         if (na > 0 && lane < m) va = border_elem<R, F>(lane, L.k1s[na - 1], L.w1s[na - 1], pap[na], dt, isq);
                         if (nb > 0 && lane < m) vb = border_elem<R, F>(lane, L.k1s[nb - 1], L.w1s[nb - 1], pap[nb], dt, isq);
                         if (nb == 0) { vint = va; th = R(0); }
-                        else if (na == 0) { th = (R)row * frcp((R)nb); vint = th * vb; }
-                        else { th = (R)(row - na) * frcp((R)(nb - na)); vint = va + th * (vb - va); }
+                        else if (na == 0) { th = (R)row * rinv[nb]; vint = th * vb; }
+                        else { th = (R)(row - na) * rinv[nb - na]; vint = va + th * (vb - va); }
                     }
                     // ---- small quasi-definite system  [[I+G11, G1x],[Gx1, Gxx - Sxx]] cc = [h1 ; hx - dX]
                     // unknown order: 0..F-1 footstep columns, F = stability row, F+1..2F = Khat_1..F (inactive: pinned to 0)
@@ -895,7 +927,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     }
                     WAVE_LDS_SYNC();
                     const unsigned long long kmask = __builtin_amdgcn_ballot_w64(klane && kact != 0);   // bit r: Khat_r active
-                    Dee = stability_defect();
+                    Dee = (R)Dd;
                     const R cc_e = solve_small(kmask);
                     const R cE = L.cc[F];
                     // ---- y = coefficients on the V columns (delta_Z - V cc = sg dt^2 k_i + V y); rows see the footstep
@@ -928,8 +960,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         if (i <= C && sk != 0) {
                             const int pv = PRV_(k), nx = NXT_(k);
                             const R sp = pv > 0 ? L.sv[pv - 1] : R(0);
-                            R r_ = (svl[k] - sp) * frcp((R)(i - pv)) * idt2 - idt * cE * abar(pv, i);
-                            if (nx > 0) r_ -= (L.sv[nx - 1] - svl[k]) * frcp((R)(nx - i)) * idt2 - idt * cE * abar(i, nx);
+                            R r_ = (svl[k] - sp) * rinv[i - pv] * idt2 - idt * cE * abar(pv, i);
+                            if (nx > 0) r_ -= (L.sv[nx - 1] - svl[k]) * rinv[nx - i] * idt2 - idt * cE * abar(i, nx);
                             if (isZ) {
                                 if (i == na) r_ += (nb == 0) ? sg : sg * (R(1) - th);
                                 if (i == nb) r_ += sg * th;
@@ -986,7 +1018,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                                 if (jj > 0) {
                                     const R sp = pv > 0 ? L.sv[pv - 1] : R(0);
                                     const R sj = (sk != 0) ? svl[k] : L.sv[jj - 1];
-                                    zu = -(sj - sp) * frcp((R)(jj - pv)) * idt - cE * (ap[i - 1] - abar(pv, jj));   // the stability multiplier
+                                    zu = -(sj - sp) * rinv[jj - pv] * idt - cE * (ap[i - 1] - abar(pv, jj));   // the stability multiplier
                                 }                                                                              // drops out of active runs
                                 if (isZ) {
                                     const R stepf = (i <= row ? R(1) : R(0)) - (i <= na ? wA : R(0)) - (i <= nb ? wB : R(0));
@@ -1015,7 +1047,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         if (isZ) {
                             if (lane < m) { L.d1[lane] = vp - va; L.d2[lane] = (nb > 0 ? vb : R(0)) - vp; L.d0[lane] = (nb > 0 ? vb : R(0)) - va; }
                             WAVE_LDS_SYNC();
-                            const R g1 = idt2 * frcp((R)(row - na)), g2 = nb > 0 ? idt2 * frcp((R)(nb - row)) : R(0), g0 = nb > 0 ? idt2 * frcp((R)(nb - na)) : R(0);
+                            const R g1 = idt2 * rinv[row - na], g2 = nb > 0 ? idt2 * rinv[nb - row] : R(0), g0 = nb > 0 ? idt2 * rinv[nb - na] : R(0);
                             for (int e = lane; e < m * m; e += 64) {
                                 const int i = e / m, jj = e - i * m;
                                 L.G[e] += g1 * L.d1[i] * L.d1[jj] + g2 * L.d2[i] * L.d2[jj] - g0 * L.d0[i] * L.d0[jj];
@@ -1029,6 +1061,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                                 if (i > row && (nb == 0 || i <= nb)) SET_PRV_(k, row);
                             }
                             ++qz;
+                            Dd += (nb > 0) ? gap_term(na, row) + gap_term(row, nb) - gap_term(na, nb)
+                                           : gap_term(na, row) + tail_term(row) - tail_term(na);
                         } else {
                             if (lane == kr) { kact = sg > R(0) ? 1 : -1; muK = mu_p; }
                             ++qk;
@@ -1047,7 +1081,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                             L.d1[lane] = vl_ - wa_; L.d2[lane] = (pb_ > 0 ? wb_ : R(0)) - vl_; L.d0[lane] = (pb_ > 0 ? wb_ : R(0)) - wa_;
                         }
                         WAVE_LDS_SYNC();
-                        const R g1 = idt2 * frcp((R)(lrow - pa_)), g2 = pb_ > 0 ? idt2 * frcp((R)(pb_ - lrow)) : R(0), g0 = pb_ > 0 ? idt2 * frcp((R)(pb_ - pa_)) : R(0);
+                        const R g1 = idt2 * rinv[lrow - pa_], g2 = pb_ > 0 ? idt2 * rinv[pb_ - lrow] : R(0), g0 = pb_ > 0 ? idt2 * rinv[pb_ - pa_] : R(0);
                         for (int e = lane; e < m * m; e += 64) {
                             const int i = e / m, jj = e - i * m;
                             L.G[e] -= g1 * L.d1[i] * L.d1[jj] + g2 * L.d2[i] * L.d2[jj] - g0 * L.d0[i] * L.d0[jj];
@@ -1061,6 +1095,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                             if (i > lrow && (pb_ == 0 || i <= pb_)) SET_PRV_(k, pa_);
                         }
                         --qz;
+                        Dd += (pb_ > 0) ? gap_term(pa_, pb_) - gap_term(pa_, lrow) - gap_term(lrow, pb_)
+                                        : tail_term(pa_) - gap_term(pa_, lrow) - tail_term(lrow);
                     } else {
                         if (lane == lrow - C) { kact = 0; muK = R(0); }
                         --qk;

@@ -1,11 +1,19 @@
 #!/bin/bash
-# residency targets for the Formulation A wave kernel: variants go to build/variants/ (ISMPC_LIB), never in-tree
+# residency targets for the Formulation A wave kernel: variants go to build/variants/ (ISMPC_LIB), never in-tree.
+# usage: scripts/occ_sweep.sh build   (here, no GPU)   |   scripts/occ_sweep.sh run   (GPU box)
 set -e
-mkdir -p build/variants; : > gpurun_out/occ_sweep.log
-for occ in 1 2 3 4; do
-  lib=$PWD/build/variants/libismpc_occ$occ.so
-  python -c "from quadruped_gait_generation_ismpc_amd import build; build.build(out='$lib', flags='-DISMPC_A_WAVE_MINBLOCKS=$occ')"
-  for leg in a_walk_C100 config3_walk_C150 a_trot_C160 config4_mc_C200; do
-    echo "occ=$occ $leg $(ISMPC_LIB=$lib timeout -k 10 300 python bench.py --only $leg --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('%.3e' % d['value'], d['roofline']['kernel_ms'])")" | tee -a gpurun_out/occ_sweep.log
-  done
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+mkdir -p build/variants gpurun_out
+VARIANTS=("a:4:3:3:2" "b:3:4:2:3" "c:5:2:2:2" "d:4:4:3:2")
+if [ "$1" = build ]; then
+  for v in "${VARIANTS[@]}"; do IFS=: read n a b c d <<< "$v"
+    python -c "from quadruped_gait_generation_ismpc_amd import build; build.build(out='build/variants/libismpc_occ_$n.so', flags='-DISMPC_A_OCC_F32_RL2=$a -DISMPC_A_OCC_F32_RL34=$b -DISMPC_A_OCC_F64_RL2=$c -DISMPC_A_OCC_F64_RL34=$d')" &
+  done; wait; ls -la build/variants; exit 0
+fi
+: > gpurun_out/occ_sweep.log
+for v in "${VARIANTS[@]}"; do IFS=: read n a b c d <<< "$v"
+  lib=$PWD/build/variants/libismpc_occ_$n.so
+  for leg in a_walk_C100 config3_walk_C150 a_trot_C160 config4_mc_C200; do for dt in f32 f64; do
+    echo "occ f32 $a/$b f64 $c/$d $leg $dt $(ISMPC_LIB=$lib timeout -k 10 120 python bench.py --only $leg --dtype $dt --no-cpu-baseline --min-region-ms 10 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('%.3e' % d['value'], d['roofline']['kernel_ms'])")" | tee -a gpurun_out/occ_sweep.log
+  done; done
 done
