@@ -461,7 +461,12 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
         gen = FA.GaitGenerator(FA.default_params(0, C=Cn, P=Pn, F=Fn), plans[0], device=R.local_rank, **kw); gen.add_plan(plans[1])
         d_inst = q.to_device(inst, R.dev)
         d0 = q.to_device(gen.initial_state(0.88, batch=batch), R.dev)
-        gen.rollout_inst_torch(d0, d_inst, MC_PREROLL)                      # nominal closed loop: spreads the gait phases
+        # data preparation, not the timed path: a nominal closed loop spreads the gait phases.  It runs on a second handle
+        # with the OTHER arithmetic type, so that its 60 cheap launches carry another kernel name and a rocprofv3 --stats
+        # summary of this process averages only the timed launches under the leg's kernel
+        prep = FA.GaitGenerator(FA.default_params(0, C=Cn, P=Pn, F=Fn), plans[0], device=R.local_rank,
+                                precision=("f32" if dtype == "f64" else "f64")); prep.add_plan(plans[1])
+        prep.rollout_inst_torch(d0, d_inst, MC_PREROLL); torch.cuda.synchronize(); prep.close()
         tick = lambda st, pu: gen.tick_inst_torch(st, d_inst, pu)
         desc = (f"Formulation A Monte-Carlo (BASELINE configs[4] per-GPU shape): trot / walk by instance parity, C={Cn}, P={Pn}, per-instance CoM height "
                 f"U(0.50,0.62), step U{{40..100}}, ds=round(0.6 step), F=ceil(C/step)+1 <= 6, Qf 1e7/1e9; {MC_PREROLL} nominal ticks then ONE pushed tick")

@@ -7,7 +7,7 @@
 # usage: scripts/profile_r02.sh [leg ...]        default: every leg bench.py reports
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=$R/gpurun_out/profiles_r02; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-LEGS=${@:-headline shard_b8192 config1_b1024 config3_walk_C150 config4_mc_C200}
+LEGS=${@:-headline shard_b8192 config1_b1024 config3_walk_C150 config3_walk_C150:f32 config4_mc_C200 config4_mc_C200:f32}
 for spec in $LEGS; do
   leg=${spec%%:*}; dt=f64; [[ $spec == *:* ]] && dt=${spec##*:}
   case $leg in
