@@ -267,11 +267,14 @@ def executed_work(leg, kernel, kernel_ms, batch):
     c = j.get("counters_mean_per_launch", {})
     ex = None
     if "SQ_INSTS_VALU" in c:
-        issue_ms = c["SQ_INSTS_VALU"] * 4.0 / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
-        ex = {"valu_insts_per_launch": c["SQ_INSTS_VALU"], "valu_issue_ms": issue_ms, "valu_issue_frac": issue_ms / kernel_ms,
+        per_step = float(j.get("launches_per_step", 1))                 # a step of the per-instance legs is several launches
+        valu = c["SQ_INSTS_VALU"] * per_step
+        issue_ms = valu * 4.0 / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
+        ex = {"valu_insts_per_launch": valu, "valu_issue_ms": issue_ms, "valu_issue_frac": issue_ms / kernel_ms,
               "mfma_insts_per_launch": c.get("SQ_INSTS_VALU_MFMA_F64", 0.0) if "SQ_INSTS_VALU_MFMA_F64" in c else None,
               "source": f"profiles/r02/pmc_{leg}.json"}
-    return ex, j.get("derived", {}).get("hbm_bytes_per_launch")
+    hbm = j.get("derived", {}).get("hbm_bytes_per_launch")
+    return ex, (hbm * float(j.get("launches_per_step", 1)) if hbm is not None else None)
 
 
 def flops_b(N):
@@ -441,8 +444,10 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
 
 def a_kernel_name(C, F, per_inst, dtype):
     rl = max(2, (C + 63) // 64)
-    pi = "true" if per_inst else "false"
-    return f"ismpc_a_tick_wave<{rl}, {F}, {pi}>"
+    real = "double" if dtype == "f64" else "float"
+    if per_inst and os.environ.get("ISMPC_A_BUCKET") == "1" and F > 3:
+        return f"ismpc_a_tick_wave<{real}, {rl}, F, true>, F = 3..{F}: one launch per footstep count (instances grouped by F_i)"
+    return f"ismpc_a_tick_wave<{real}, {rl}, {F}, {'true' if per_inst else 'false'}>"
 
 
 def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):

@@ -12,7 +12,8 @@ constexpr int MAXF = 8;
 
 struct DevA {
     int C, P, F, step, ds, n_gait, ncl, ldq, max_iter, sinv_in_lds;
-    int warm_add, warm_drop, warm_extra; // block warm start of the wave kernel: passes that add + drop rows, passes that only drop, re-entries
+    int warm_add, warm_drop, warm_extra, warm_min_viol; // block warm start of the wave kernel: passes that add + drop rows, passes that only drop,
+                                         // re-entries into adding passes, violated rows that make a re-entry worth it
     double dt, eta, w, Qf, disp_forw, disp_forw_dummy, disp_L, aa, wP, sumw;
     double Au[9], Bu[3];
     const double *a, *PA, *PA2, *wtail; // stability row, prefix sums PA[i] = sum_{k<i} a_k and PA2[i] = sum_{k<i} a_k^2, tail weights (index i-(C+1))
@@ -28,7 +29,8 @@ struct WaveLaunch {
     const DevA* c_dev; int F;                      // the handle's constants in device memory; footsteps in the horizon (kernel shape)
     const ismpc_a_state* prev; ismpc_a_state* state; const ismpc_a_inst* inst; const double* push; ismpc_a_out* out;
     int batch; int* work_counter; unsigned long long* hist; int hist_load;
-    int precision; int cus; int* occ_cache;       // occ_cache: 4 ints per handle (precision x per-instance), 0 = not queried yet
+    int precision; int cus; int* occ_cache;       // occ_cache: per handle, [F - 3][precision x per-instance], 0 = not queried yet
+    const int* order; const int* count_ptr;       // NULL, or the instances of this launch (device list + device count): see tick_launch
     hipStream_t stream;
 };
 

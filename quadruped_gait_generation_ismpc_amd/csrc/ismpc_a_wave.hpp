@@ -255,7 +255,8 @@ template <typename R, int RL, int F, bool PI>
 __global__ __launch_bounds__(WG, (wave_min_blocks<R, RL>()))
 void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
                        const ismpc_a_inst* __restrict__ ipar, const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch,
-                       int* __restrict__ work_counter, unsigned long long* __restrict__ hist, int hist_load)
+                       int* __restrict__ work_counter, unsigned long long* __restrict__ hist, int hist_load,
+                       const int* __restrict__ order, const int* __restrict__ count_ptr)
 {
     using NM = Num<R>;
     const DevA& c = *cp;                                   // handle constants, read from memory where they are used (by value they would
@@ -290,8 +291,11 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         int claimed = 0;
         if (lane == 0) claimed = atomicAdd(work_counter, 1);
         const int work = __builtin_amdgcn_readfirstlane(claimed);
-        if (work >= 2 * batch) break;
-        const int inst = work >> 1, axis = work & 1;
+        // instances of this launch: all `batch` of them, or the `*count_ptr` listed in `order` (per-instance parameters: the
+        // host sorts the instances by their footstep count and runs each group through the kernel of that shape)
+        if (work >= 2 * (count_ptr ? *count_ptr : batch)) break;
+        const int inst = order ? order[work >> 1] : (work >> 1), axis = work & 1;
+        const int qp = 2 * inst + axis;                    // slot of this QP in the working-set history
         const ismpc_a_state st = state_in[inst];
         const double pos = axis == 0 ? st.x : st.y;
         const double vel = (axis == 0 ? st.xd : st.yd) + (push ? push[inst * 2 + axis] : 0.0);
@@ -352,6 +356,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         // ks = first mapped footstep (bits 0-3) | row state + 1 (bits 4-5: 0 upper active, 1 free, 2 lower active);
         // pn = previous active row (bits 0-15) | next active row (bits 16-31), kept for every row, active or not
         R u[RL], w1[RL], mu[RL];
+        float inrm[RL];
             int ks[RL], pn[RL];
 #define K1_(k_)  (ks[k_] & 15)
 #define STA_(k_) (((ks[k_] >> 4) & 3) - 1)
@@ -374,8 +379,12 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 ovf = ovf || pf > Fi || (rem <= ds_ && pf + 1 > Fi);
                 if (pf > 15) pf = 15;
                 ks[k] = pf | (1 << 4);
+                {   // 1 / |row_i|_{H^-1} (float: it only ranks candidates): |row|^2 = dt^2 i + |M_i|^2 / Qf over the footstep columns
+                    const float w1f = (float)w1[k], w2f = 1.0f - w1f;
+                    inrm[k] = rsq_f((float)(c.dt * c.dt) * (float)i + (w2f * w2f + (pf >= 1 ? w1f * w1f : 0.0f)) * (float)iQf);
+                }
                 L.k1s[i - 1] = (unsigned char)pf; L.w1s[i - 1] = w1[k];
-            } else { w1[k] = R(1); ks[k] = 1 << 4; }
+            } else { w1[k] = R(1); ks[k] = 1 << 4; inrm[k] = 0.0f; }
         }
         if (__builtin_amdgcn_ballot_w64(ovf) != 0) status |= ISMPC_A_ST_OVERFLOW;
         // anticipative tail (quad_walk_no_plots.m:227-231)
@@ -545,8 +554,6 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 // over the wavefront (fold_step: about one exchange-add per sum instead of six).
                 {
                     constexpr int NT = F * (F + 1) / 2, NR = 2 * F + 2;
-                    // two sweeps over the lane's rows -- Theta (NT sums), then psi, gamma, sigma, gamma_E (NR sums) -- keep the live
-                    // accumulators at max(NT, NR) instead of NT + NR; the per-row differences are cheap to form twice
                     auto pair_diffs = [&](int k, R (&dth)[F], R& om, R& dE, R& dc) __attribute__((always_inline)) {
                         const int i = lane * RL + k + 1;
                         const int p_ = PRV_(k);
@@ -564,9 +571,10 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         }
                     };
                     {
-                        R acc[NT];
+                        constexpr int NS = NT + NR;
+                        R acc[NS];
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) acc[t] = R(0);
+                        for (int t = 0; t < NS; ++t) acc[t] = R(0);
 #pragma unroll
                         for (int k = 0; k < RL; ++k) {
                             const int i = lane * RL + k + 1;
@@ -579,27 +587,12 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                                     const R od = om * dth[r];
 #pragma unroll
                                     for (int q = r; q < F; ++q) acc[t++] += od * dth[q];
+                                    acc[NT + r] += od * dE; acc[NT + F + r] += od * dc;
                                 }
+                                acc[NT + 2 * F] += om * dE * dE; acc[NT + 2 * F + 1] += om * dE * dc;
                             }
                         }
-                        wave_fold_sums<R, NT>(acc, L.th, lane);
-                    }
-                    {
-                        R acc[NR];
-#pragma unroll
-                        for (int t = 0; t < NR; ++t) acc[t] = R(0);
-#pragma unroll
-                        for (int k = 0; k < RL; ++k) {
-                            const int i = lane * RL + k + 1;
-                            if (i <= C && STA_(k) != 0) {
-                                R dth[F], om, dE, dc;
-                                pair_diffs(k, dth, om, dE, dc);
-#pragma unroll
-                                for (int r = 0; r < F; ++r) { const R od = om * dth[r]; acc[r] += od * dE; acc[F + r] += od * dc; }
-                                acc[2 * F] += om * dE * dE; acc[2 * F + 1] += om * dE * dc;
-                            }
-                        }
-                        wave_fold_sums<R, NR>(acc, L.th + NT, lane);
+                        wave_fold_sums<R, NS>(acc, L.th, lane);
                     }
                     WAVE_LDS_SYNC();
                     // Phi(e): e < F -> +col e+1 ; e > F -> -col (e-F) + col (e-F-1) [if >= 1] ; all scaled by 1/sqrt(Qf)
@@ -714,7 +707,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #pragma unroll
                 for (int k = 0; k < RL; ++k) guess[k] = 0;
                 if (hist != nullptr && hist_load) {
-                    const unsigned long long* hq = hist + (size_t)work * 8;
+                    const unsigned long long* hq = hist + (size_t)qp * 8;
                     unsigned long long any_ = 0ull;
 #pragma unroll
                     for (int k = 0; k < RL; ++k) {
@@ -807,7 +800,19 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         if (__builtin_amdgcn_ballot_w64(off_bound) != 0 || !(fabs(eqr) <= (R)NM::eq_rel * (R(1) + fabs(beq)))) { cold = true; break; }
                     }
                     if (__builtin_amdgcn_ballot_w64(changed) == 0) {               // a valid pair (and, while adding, nothing violated)
-                        if (!adding && extra > 0) { --extra; force_add = true; continue; }   // valid after drop-only passes: one more adding pass
+                        if (!adding && extra > 0) {
+                            // valid after drop-only passes.  Goldfarb-Idnani would now take the violated rows one at a time; when
+                            // many are left, one more adding pass (all of them at once) is the cheaper way on
+                            int nv = 0;
+#pragma unroll
+                            for (int k = 0; k < RL; ++k) {
+                                const int i = lane * RL + k + 1;
+                                const R v = vv[k];
+                                const R tol = (R)NM::viol_rel * (fabs(v) + fmax(fabs(zlo), fabs(zhi))) + (R)NM::viol_abs;
+                                nv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(i <= C && STA_(k) == 0 && (v - zlo < -tol || zhi - v < -tol)));
+                            }
+                            if (nv >= c.warm_min_viol) { --extra; force_add = true; continue; }
+                        }
                         if (adding && nsolve > 0) {
                             // every ZMP row was just evaluated at this point (none violated, active ones on their bounds, the
                             // stability row holds, multipliers positive); with the kinematic rows inside their limits this
@@ -849,9 +854,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                             const R v = vv[k];
                             const R vl = v - zlo, vh = zhi - v;
                             const R tol = (R)NM::viol_rel * (fabs(v) + fmax(fabs(zlo), fabs(zhi))) + (R)NM::viol_abs;
-                            // 1 / |row_i|_{H^-1} (float: it only ranks candidates): |row|^2 = dt^2 i + |M_i|^2 / Qf over the footstep columns
-                            const float w1f = (float)w1[k], w2f = 1.0f - w1f;
-                            const R nr = (R)rsq_f((float)(c.dt * c.dt) * (float)i + (w2f * w2f + (K1_(k) >= 1 ? w1f * w1f : 0.0f)) * (float)iQf);
+                            const R nr = (R)inrm[k];
                             if (vl < -tol && vl * nr < cand) { cand = vl * nr; craw = vl; code = 2 * i; }
                             if (vh < -tol && vh * nr < cand) { cand = vh * nr; craw = vh; code = 2 * i + 1; }
                         }
@@ -1151,7 +1154,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         }
 
         if (hist != nullptr) {
-            unsigned long long* hq = hist + (size_t)work * 8;
+            unsigned long long* hq = hist + (size_t)qp * 8;
 #pragma unroll
             for (int k = 0; k < RL; ++k) {
                 const unsigned long long lo_ = __builtin_amdgcn_ballot_w64(status == 0 && STA_(k) > 0), hi_ = __builtin_amdgcn_ballot_w64(status == 0 && STA_(k) < 0);
@@ -1209,14 +1212,15 @@ template <typename R, int RL, int F, bool PI>
 inline int launch_one(const WaveLaunch& L, hipError_t* err)
 {
     auto kern = ismpc_a_tick_wave<R, RL, F, PI>;
-    int& occ = L.occ_cache[(sizeof(R) == 4 ? 2 : 0) + (PI ? 1 : 0)];
+    int& occ = L.occ_cache[(F - 3) * 4 + (sizeof(R) == 4 ? 2 : 0) + (PI ? 1 : 0)];
     if (occ == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WG, 0) != hipSuccess || nb < 1) nb = 1;
         occ = nb;
     }
     const int grid = std::min((2 * L.batch + 3) / 4, L.cus * occ);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), 0, L.stream, L.c_dev, L.prev, L.state, L.inst, L.push, L.out, L.batch, L.work_counter, L.hist, L.hist_load);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), 0, L.stream, L.c_dev, L.prev, L.state, L.inst, L.push, L.out, L.batch, L.work_counter, L.hist, L.hist_load,
+                       L.order, L.count_ptr);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = e; return -2; }
     return 0;

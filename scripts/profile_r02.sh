@@ -29,7 +29,8 @@ for spec in $LEGS; do
   run mem TA_TA_BUSY_sum TA_FLAT_LOAD_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE
   run fetch FETCH_SIZE
   run write WRITE_SIZE
-  python3 $R/scripts/pmc_summary.py $OUT/tmp_$key "$kern" $OUT/pmc_$key.json batch=$batch leg=\"$key\" > /dev/null
+  per_step=1; [[ $leg == config4_mc_C200 && "$ISMPC_A_BUCKET" == 1 ]] && per_step=4      # opt-in: one kernel per footstep count 3..6
+  python3 $R/scripts/pmc_summary.py $OUT/tmp_$key "$kern" $OUT/pmc_$key.json batch=$batch leg=\"$key\" launches_per_step=$per_step > /dev/null
   grep -E "valu_insts_per_wave|hbm_bytes_per_launch|wave_cycles_per_wave" $OUT/pmc_$key.json | tr -d '\n'; echo
   head -3 $OUT/${key}_kernel_stats.csv | cut -c1-160
   rm -rf $OUT/tmp_$key/*/*/*agent_info.csv

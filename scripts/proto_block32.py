@@ -125,3 +125,46 @@ if __name__ == "__main__":
             print(f"t={t} ax={axis} |W|={len(Wz)}  f64: res {out[np.float64][0]:.1e} viol {out[np.float64][1]:.1e} du {out[np.float64][3]:.1e} | "
                   f"f32: res {out[np.float32][0]:.1e} viol {out[np.float32][1]:.1e} minmu {out[np.float32][2]:.2e} du {out[np.float32][3]:.1e} df {out[np.float32][4]:.1e}")
         sim.state = st
+
+
+def first_pass_study(name, ntest=40):
+    """What does the FIRST adding pass of the block warm start see?  From the equality-only point u = (b / a'a) a every violated
+    row enters at once; is the structured solve on that set well posed (active rows back on their bounds, stability row met)?"""
+    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"prerollA_{name}.npz"))
+    kind = int(z["gait"]); p = A.params(kind, C_=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
+    sim = A.SimA(A.gait(kind, float(z["phi"]), float(z["disp_A"])), p, backend="gi")
+    rng = np.random.default_rng(1)
+    sim.run(int(rng.integers(5, 150)))
+    eta = np.sqrt(p.grav / p.height)
+    os.environ["EXACT_D"] = "1"
+    bad = 0; tot = 0
+    for t in range(ntest):
+        sim.run(int(rng.integers(1, 12)))
+        st = sim.state.copy()
+        st2 = st.copy(); st2["xd"] += rng.uniform(-0.03, 0.03); st2["yd"] += rng.uniform(-0.05, 0.05)
+        sim.state = st2
+        for axis in (0, 1):
+            D = sim.axis_data(axis); cur = float(st["cur_x"] if axis == 0 else st["cur_y"])
+            a = D["a"]; C = len(a); M = D["M"]
+            u = (D["b"] / (a @ a)) * a
+            f = D["pref"]
+            v = p.dt * np.cumsum(u) - M[:, 1:] @ f
+            W = {}
+            for i in range(C):
+                if v[i] < D["zlo"][i] - 1e-12: W[i] = +1
+                elif v[i] > D["zhi"][i] + 1e-12: W[i] = -1
+            if not W: continue
+            tot += 1
+            uu, ff, vv, mu, zlo, zhi, rows, sgn = block_solve(D, cur, W, p.dt, p.Qf, eta, np.float64)
+            res = max(abs(float(vv[i - 1]) - float(zlo if sgn[i] > 0 else zhi)) for i in rows)
+            eqr = abs(float(a @ uu) - D["b"])
+            nneg = sum(1 for m_ in mu.values() if m_ <= 0)
+            lo_n = sum(1 for s_ in sgn.values() if s_ > 0); hi_n = len(sgn) - lo_n
+            flag = res > 1e-8 * 0.4 + 1e-10 or eqr > 1e-8 * (1 + abs(D["b"]))
+            bad += flag
+            print(f"t={t} ax={axis} |W1|={len(W)} (lo {lo_n} hi {hi_n}) res {res:.1e} eqr {eqr:.1e} neg-mult {nneg} max|u| {np.abs(uu).max():.2e} {'<-- CHECK FAILS' if flag else ''}")
+        sim.state = st
+    print("first pass check fails:", bad, "of", tot)
+
+if __name__ == "__main__" and os.environ.get("FIRST"):
+    first_pass_study(sys.argv[1] if len(sys.argv) > 1 else "walk_C150", int(sys.argv[2]) if len(sys.argv) > 2 else 30)
