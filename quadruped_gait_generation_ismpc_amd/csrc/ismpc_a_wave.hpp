@@ -35,8 +35,8 @@ namespace ismpc_a {
 template <typename R> struct Num;
 template <> struct Num<double> {
     static constexpr double viol_rel = 1e-11, viol_abs = 1e-13;     // a row is violated beyond  rel (|v| + |bounds|) + abs
-    static constexpr double bound_rel = 1e-8, bound_abs = 1e-10;    // block solve: active rows must sit on their bounds
-    static constexpr double eq_rel = 1e-8;                          // ... and the stability row must hold
+    static constexpr double bound_rel = 1e-6, bound_abs = 1e-8;     // block solve: active rows must sit on their bounds (a breakdown
+    static constexpr double eq_rel = 1e-6;                          // is off by orders of magnitude more) and the stability row must hold
     static constexpr double gamma_rel = 1e-12;                      // full step possible when gamma > rel |n+|^2
     static constexpr double final_rel = 1e-6, final_abs = 1e-7;     // check of the returned point (band half-width: 1e-2)
     static constexpr double mult_rel = 1e-8;                        // polish: multipliers may be this negative
