@@ -244,15 +244,16 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 #ifndef ISMPC_A_OCC_F64_RL34
 #define ISMPC_A_OCC_F64_RL34 2
 #endif
-template <typename R, int RL> constexpr int wave_min_blocks()
+template <typename R, int RL, bool PI> constexpr int wave_min_blocks()
 {
+    if (PI && sizeof(R) == 8 && RL <= 2) return 2;         // 56-62 KB of LDS per workgroup: two fit a CU whatever the registers allow
     return sizeof(R) == 4 ? (RL <= 2 ? ISMPC_A_OCC_F32_RL2 : ISMPC_A_OCC_F32_RL34) : (RL <= 2 ? ISMPC_A_OCC_F64_RL2 : ISMPC_A_OCC_F64_RL34);
 }
 
 // RL = ZMP rows per lane (C <= 64 RL), F = footsteps in the horizon (m = 2F+1 border columns).
 // PI: per-instance gait parameters (ismpc_a_inst): height, Qf, step, ds, F <= the template F, base plan.
 template <typename R, int RL, int F, bool PI>
-__global__ __launch_bounds__(WG, (wave_min_blocks<R, RL>()))
+__global__ __launch_bounds__(WG, (wave_min_blocks<R, RL, PI>()))
 void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
                        const ismpc_a_inst* __restrict__ ipar, const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch,
                        int* __restrict__ work_counter, unsigned long long* __restrict__ hist, int hist_load,

@@ -1198,7 +1198,22 @@ struct QOut { double x, y, z, xd, yd, zd, uz0, ux0, uy0; int status, itx, ity; }
 template <int R> constexpr int midm() { return R | 1; }
 template <int R, int LPI> constexpr int wave_lds_double2() { return (64 / LPI) * LPI * midm<R>(); }
 
-template <int R, int LPI>
+// KF: how the knapsack Newton loop is scheduled, not what it computes (the iterates are bit-identical): 0 = count the saturated
+// samples first and form the two sums only for axes that still move (fewest instructions: batches that fill the chip are
+// VALU-issue bound); 1 = count and sums of both axes in one pass, six interleaved group reductions instead of up to three
+// dependent ones per axis.  Measured (scripts/kf_sweep.sh, MI355X): 1 is slower at every batch size -- 10.2 vs 9.7 us at 1 024
+// instances, 14.0 vs 12.8 at 8 192, 51.8 vs 46.7 at 65 536, 5.9 vs 5.4 us per tick in the rollout kernel -- even one wavefront
+// alone on its SIMD is bound by the number of instructions it issues, not by the reduction chains.  Kept as a build-time knob.
+#ifndef ISMPC_KF_INLINE
+#define ISMPC_KF_INLINE 0
+#endif
+#ifndef ISMPC_KF_MAIN
+#define ISMPC_KF_MAIN 0
+#endif
+#ifndef ISMPC_KF_ROLLOUT
+#define ISMPC_KF_ROLLOUT 0
+#endif
+template <int R, int LPI, int KF>
 __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lane, const QState& s, QOut& o, double* __restrict__ u_traj_inst,
                                                 double2* __restrict__ lds_wave)
 {
@@ -1370,30 +1385,67 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
             if (Tq[ax] > 1e-300) st3 |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
         }
     }
-    for (int it = 0; it < N + 2; ++it) {
-        if (__builtin_amdgcn_ballot_w64(live[0] || live[1]) == 0ull) break;
+    if constexpr (KF == 0) {
+        for (int it = 0; it < N + 2; ++it) {
+            if (__builtin_amdgcn_ballot_w64(live[0] || live[1]) == 0ull) break;
 #pragma unroll
-        for (int ax = 0; ax < 2; ++ax) {
-            int cl = 0;
+            for (int ax = 0; ax < 2; ++ax) {
+                int cl = 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) cl += (tau[ax] * fabs(a[r]) >= h) ? 1 : 0;
-            const int cnt = Grp<LPI>::sum_i(cl);
-            if (live[ax] && cnt == prev[ax]) live[ax] = false;                // active set unchanged: exact
-            if (__builtin_amdgcn_ballot_w64(live[ax]) == 0ull) continue;
-            double ssat = 0.0, qfree = 0.0;
+                for (int r = 0; r < R; ++r) cl += (tau[ax] * fabs(a[r]) >= h) ? 1 : 0;
+                const int cnt = Grp<LPI>::sum_i(cl);
+                if (live[ax] && cnt == prev[ax]) live[ax] = false;                // active set unchanged: exact
+                if (__builtin_amdgcn_ballot_w64(live[ax]) == 0ull) continue;
+                double ssat = 0.0, qfree = 0.0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const bool sat = tau[ax] * fabs(a[r]) >= h; ssat += sat ? fabs(a[r]) : 0.0; const double a2 = a[r] * a[r]; qfree += sat ? 0.0 : a2; }
-            ssat = Grp<LPI>::sum(ssat); qfree = Grp<LPI>::sum(qfree);
-            if (live[ax]) {
-                ++its[ax];
-                const double rem = fma(-h, ssat, Tq[ax]);
-                if (!(qfree > 0.0)) {                                         // everything saturated
-                    if (rem > fma(h * ssat, 1e-12, 1e-300)) st3 |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
-                    tau[ax] = INFINITY; live[ax] = false;
-                } else {
-                    const double tn = rem * frcp(qfree);
-                    if (!(tn > tau[ax])) live[ax] = false;
-                    else { tau[ax] = tn; prev[ax] = cnt; }
+                for (int r = 0; r < R; ++r) { const bool sat = tau[ax] * fabs(a[r]) >= h; ssat += sat ? fabs(a[r]) : 0.0; const double a2 = a[r] * a[r]; qfree += sat ? 0.0 : a2; }
+                ssat = Grp<LPI>::sum(ssat); qfree = Grp<LPI>::sum(qfree);
+                if (live[ax]) {
+                    ++its[ax];
+                    const double rem = fma(-h, ssat, Tq[ax]);
+                    if (!(qfree > 0.0)) {                                         // everything saturated
+                        if (rem > fma(h * ssat, 1e-12, 1e-300)) st3 |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
+                        tau[ax] = INFINITY; live[ax] = false;
+                    } else {
+                        const double tn = rem * frcp(qfree);
+                        if (!(tn > tau[ax])) live[ax] = false;
+                        else { tau[ax] = tn; prev[ax] = cnt; }
+                    }
+                }
+            }
+        }
+    } else {
+        for (int it = 0; it < N + 2; ++it) {
+            if (__builtin_amdgcn_ballot_w64(live[0] || live[1]) == 0ull) break;
+            int cl[2] = {0, 0};
+            double ssat[2] = {0.0, 0.0}, qfree[2] = {0.0, 0.0};
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool sat = tau[ax] * fabs(a[r]) >= h;
+                    cl[ax] += sat ? 1 : 0; ssat[ax] += sat ? fabs(a[r]) : 0.0;
+                    const double a2 = a[r] * a[r]; qfree[ax] += sat ? 0.0 : a2;
+                }
+            }
+            const int cnt0 = Grp<LPI>::sum_i(cl[0]), cnt1 = Grp<LPI>::sum_i(cl[1]);
+            ssat[0] = Grp<LPI>::sum(ssat[0]); ssat[1] = Grp<LPI>::sum(ssat[1]);
+            qfree[0] = Grp<LPI>::sum(qfree[0]); qfree[1] = Grp<LPI>::sum(qfree[1]);
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) {
+                const int cnt = ax == 0 ? cnt0 : cnt1;
+                if (live[ax] && cnt == prev[ax]) live[ax] = false;            // active set unchanged: exact
+                if (live[ax]) {
+                    ++its[ax];
+                    const double rem = fma(-h, ssat[ax], Tq[ax]);
+                    if (!(qfree[ax] > 0.0)) {                                 // everything saturated
+                        if (rem > fma(h * ssat[ax], 1e-12, 1e-300)) st3 |= (ax == 0 ? ISMPC_ST_X_INFEASIBLE : ISMPC_ST_Y_INFEASIBLE);
+                        tau[ax] = INFINITY; live[ax] = false;
+                    } else {
+                        const double tn = rem * frcp(qfree[ax]);
+                        if (!(tn > tau[ax])) live[ax] = false;
+                        else { tau[ax] = tn; prev[ax] = cnt; }
+                    }
                 }
             }
         }
@@ -1461,7 +1513,7 @@ __device__ __forceinline__ void store_feedback(const DevConst& c, ismpc_tick_in*
 }
 
 // One launch = one tick: record in, record out (and, in the host-driven closed loop, state fed back in place)
-template <int R, int LPI>
+template <int R, int LPI, int KF>
 __device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_raw, const int batch, const int lane,
                                                 const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                                                 ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
@@ -1477,7 +1529,7 @@ __device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_
     s.x = rec->com_pos[0]; s.y = rec->com_pos[1]; s.z = rec->com_pos[2];
     s.xd = rec->com_vel[0]; s.yd = rec->com_vel[1]; s.zd = rec->com_vel[2];
     QOut o;
-    const bool deferred = tick_group_core<R, LPI>(c, lane, s, o, (u_traj && valid) ? u_traj + (size_t)gi * 3 * c.N : nullptr, lds_wave);
+    const bool deferred = tick_group_core<R, LPI, KF>(c, lane, s, o, (u_traj && valid) ? u_traj + (size_t)gi * 3 * c.N : nullptr, lds_wave);
     if ((lane & (LPI - 1)) == 0 && valid) {
         if (out) store_record(out + gi, o);
         if (zmark) zmark[gi] = deferred ? 1 : 0;
@@ -1503,7 +1555,7 @@ void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, 
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
     if (wave * IPW >= batch) return;
-    tick_group_body<R, LPI>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
+    tick_group_body<R, LPI, ISMPC_KF_MAIN>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
 }
 
 // Latency variant for small batches (every wavefront resident at once): a wavefront that deferred one of its
@@ -1520,7 +1572,7 @@ void ismpc_tick_quad_inline(const DevConst c, const ismpc_tick_in* __restrict__ 
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
     if (wave * IPW >= batch) return;
-    const bool def = tick_group_body<R, LPI>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
+    const bool def = tick_group_body<R, LPI, ISMPC_KF_INLINE>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
     unsigned long long m = __builtin_amdgcn_ballot_w64(def);
     if (m == 0ull) return;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1570,7 +1622,7 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
             if (s.w.fc >= 0 && s.w.fc < c.rows && s.w.sim >= c.ftsp_t[s.w.fc] - 1) { s.w.ctl = 0; s.w.mpc = 0; s.w.fc = s.w.fc + 1; }
             s.w.sim = (double)frame;
             QOut o;
-            const bool def = tick_group_core<R, LPI>(c, lane, s, o, nullptr, lds_mid[wv]);
+            const bool def = tick_group_core<R, LPI, ISMPC_KF_ROLLOUT>(c, lane, s, o, nullptr, lds_mid[wv]);
             const bool park = def && alive;
             if (li == 0 && valid && alive && !def && traj) store_record(traj + (size_t)t * batch + gi, o);
             // a deferred instance: its pre-tick state goes to memory (FB = false: to stay there; FB = true: for the fallback body)
