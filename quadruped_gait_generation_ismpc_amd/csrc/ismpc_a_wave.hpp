@@ -354,7 +354,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         }
 
         // ---- per-row data: lane owns ZMP rows lane*RL+1 .. lane*RL+RL (row i = sample i, u index i-1).
-        // ks = first mapped footstep (bits 0-3) | row state + 1 (bits 4-5: 0 upper active, 1 free, 2 lower active);
+        // ks = first mapped footstep (bits 0-3) | row state + 1 (bits 4-5: 0 upper active, 1 free, 2 lower active) | peel (bits 6-8);
         // pn = previous active row (bits 0-15) | next active row (bits 16-31), kept for every row, active or not
         R u[RL], w1[RL], mu[RL];
         float inrm[RL];
@@ -362,6 +362,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #define K1_(k_)  (ks[k_] & 15)
 #define STA_(k_) (((ks[k_] >> 4) & 3) - 1)
 #define SET_STA_(k_, s_) (ks[k_] = (ks[k_] & 15) | (((s_) + 1) << 4))
+#define PC_(k_) ((ks[k_] >> 6) & 7)                     /* bits 6-8: log2 of the peel length of a run end (block passes only; SET_STA_ clears it) */
 #define PRV_(k_) (pn[k_] & 0xffff)
 #define NXT_(k_) ((int)((unsigned)pn[k_] >> 16))
 #define SET_PRV_(k_, p_) (pn[k_] = (pn[k_] & ~0xffff) | (p_))
@@ -420,6 +421,9 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         }
         const R knrm = (lane >= 2) ? sq * R(0.70710678118654752440) : sq;   // 1 / |K_r|_{H^-1}: |kvec_r|^2 = 2 (r >= 2) or 1
         int iters = 0, qz = 0, qk = 0;
+#ifdef ISMPC_A_DIAG
+        int dg_ns = 0, dg_cold = 0, dg_q0 = 0, dg_part = 0, dg_why = 0;   // diagnostic build (scripts/iters_hist.py): see the packing at the output
+#endif
         R muE = R(0);
         bool done_opt = false;                                // the block passes ended on a checked optimum: nothing left to do
         if (status == 0) {
@@ -698,27 +702,46 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             // and a suffix sum.  Up to c.warm_drop more passes only remove rows with negative multipliers.  What is left is a
             // valid starting pair for Goldfarb-Idnani (minimiser on its working set, multipliers >= 0), which finishes the
             // job and owns the kinematic rows; if the passes do not get there the solve starts cold.  Same optimum either way.
-            if (c.warm_add > 0) {
+            // closed loop: the working set this instance ended the previous tick with is the first guess of the block passes
+            bool have_guess = false;
+            if (c.warm_add > 0 && hist != nullptr && hist_load) {
+                const unsigned long long* hq = hist + (size_t)qp * 8;
+                unsigned long long any_ = 0ull;
+#pragma unroll
+                for (int k = 0; k < 2 * 4; ++k) any_ |= hq[k];
+                have_guess = any_ != 0ull;
+            }
+            // Three phases share one Goldfarb-Idnani loop.  phase 0 (one-shot ticks): up to c.warm_gi rows enter one at a time
+            // from the equality-only point -- its violated stretch is a poor predictor of the optimal working set (a long
+            // violated run often ends as one or two touching points), the stretch left after two or three exact steps is a
+            // good one; phase 1: the block passes, from wherever phase 0 stopped (or from the previous tick's working set);
+            // phase 2: Goldfarb-Idnani to the end.  Between 1 and 2, up to c.warm_rounds rounds of (c.warm_round_adds more
+            // Goldfarb-Idnani additions, then the passes again): when the passes collapse -- an over-constrained intermediate
+            // set turns most multipliers negative at once and the drop-only passes strip the set to a row or two -- the exact
+            // steps re-seed them instead of re-adding a hundred rows one at a time.
+            int phase = (c.warm_add <= 0) ? 2 : ((c.warm_gi > 0 && !have_guess) ? 0 : 1);
+            int gi_limit = c.warm_gi, rounds_left = c.warm_rounds;
+            int pass_solves = 0; bool pass_cold = false;          // what the last run of the passes did
+            for (;;) {
+            if (phase == 1) {
+                phase = 2;
                 bool cold = false, force_add = false;
-                int peel = 1, extra = c.warm_extra, nsolve = 0;
-                // closed loop: the working set this instance ended the previous tick with, moved down by one row (the
-                // horizon advanced by one sample), is the first guess; any guess is safe, the passes validate it
+                int extra = c.warm_extra, nsolve = 0;
+                int peel = 1;
+                // the previous tick's working set, moved down by one row (the horizon advanced by one sample); any guess is
+                // safe, the passes validate it
                 int guess[RL];
-                bool have_guess = false;
 #pragma unroll
                 for (int k = 0; k < RL; ++k) guess[k] = 0;
-                if (hist != nullptr && hist_load) {
+                if (have_guess) {
                     const unsigned long long* hq = hist + (size_t)qp * 8;
-                    unsigned long long any_ = 0ull;
 #pragma unroll
                     for (int k = 0; k < RL; ++k) {
                         const unsigned long long lo_ = (k < RL - 1) ? hq[k + 1] : (hq[0] >> 1);          // rows on the lower bound
                         const unsigned long long hi_ = (k < RL - 1) ? hq[4 + k + 1] : (hq[4] >> 1);      // rows on the upper bound
                         const int i = lane * RL + k + 1;
                         if (i <= C) guess[k] = ((lo_ >> lane) & 1ull) ? 1 : (((hi_ >> lane) & 1ull) ? -1 : 0);
-                        any_ |= lo_ | hi_;
                     }
-                    have_guess = any_ != 0ull;
                 }
                 for (int pass = 0; ; ++pass) {
                     const bool adding = pass < c.warm_add || force_add;
@@ -728,16 +751,20 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     row_values(vv);
                     // ---- rows that leave: multiplier not positive (while adding) / negative (drop-only passes).  Such a row
                     // usually sits at the end of a run of consecutive rows on the same bound, and the run has to shrink by
-                    // more than one row ("peeling"): every pass in a row that still finds one doubles the number of rows
-                    // taken off that end (peel).  Taking off too many is harmless, they come back as violated rows.
+                    // more than one row ("peeling"): an end that is negative again one pass after it was cut has twice as many
+                    // rows taken off (each run end keeps its own length, on the row that becomes the new end; with
+                    // c.warm_peel_end = 0 one length per QP, doubled while any row is negative).  Taking off too many costs
+                    // little while rows are still being added: they come back as violated rows.
                     bool xdrop[RL], negr[RL], anyneg = false;
+                    int pcn[RL];
+                    const bool per_end = c.warm_peel_end != 0;
 #pragma unroll
                     for (int k = 0; k < RL; ++k) {
                         negr[k] = STA_(k) != 0 && (adding ? !(mu[k] > R(0)) : (mu[k] < R(0)));
-                        xdrop[k] = false; anyneg = anyneg || negr[k];
+                        xdrop[k] = false; anyneg = anyneg || negr[k]; pcn[k] = 0;
                     }
                     const bool wave_neg = __builtin_amdgcn_ballot_w64(anyneg) != 0;
-                    if (peel > 1 && wave_neg) {
+                    if (wave_neg && (per_end || peel > 1)) {
                         const int sprev = dpp_i<0x138, 0xf>(0, STA_(RL - 1)), snext = dpp_i<0x130, 0xf>(0, STA_(0));
                         int lst = 0, len_ = 1 << 30;                            // this lane's last run start / first run end
                         bool isst[RL], isen[RL];
@@ -749,7 +776,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                             isst[k] = sk != 0 && sb != sk; isen[k] = sk != 0 && sa != sk;
                             if (isst[k]) lst = i;
                             if (isen[k]) len_ = min(len_, i);
-                            if (i <= C) L.sv[i - 1] = negr[k] ? R(1) : R(0);
+                            if (i <= C) L.sv[i - 1] = negr[k] ? (R)(per_end ? (1 << PC_(k)) : peel) : R(0);   // rows to take off if this is a run end
                         }
                         int runlo[RL], runhi[RL];
                         int run = dpp_i<0x138, 0xf>(0, wave_scan_max_i(lst));
@@ -765,8 +792,12 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         for (int k = 0; k < RL; ++k) {
                             const int i = lane * RL + k + 1;
                             if (STA_(k) != 0 && runlo[k] >= 1 && runhi[k] <= C && runlo[k] != runhi[k]) {
-                                if (i - runlo[k] < peel && L.sv[runlo[k] - 1] != R(0)) xdrop[k] = true;
-                                if (runhi[k] - i < peel && L.sv[runhi[k] - 1] != R(0)) xdrop[k] = true;
+                                const int dl = (int)L.sv[runlo[k] - 1], dh = (int)L.sv[runhi[k] - 1];      // 0: that end is not negative
+                                if (i - runlo[k] < dl || runhi[k] - i < dh) xdrop[k] = true;
+                                if (per_end) {                                                            // the row that becomes the new end
+                                    if (dl > 0 && i - runlo[k] == dl) pcn[k] = min(32 - __builtin_clz(dl), 6);
+                                    if (dh > 0 && runhi[k] - i == dh) pcn[k] = max(pcn[k], min(32 - __builtin_clz(dh), 6));
+                                }
                             }
                         }
                         WAVE_LDS_SYNC();
@@ -794,11 +825,17 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                             }
                             changed = changed || ns != os;
                             SET_STA_(k, ns);
+                            ks[k] |= pcn[k] << 6;
                         }
                     }
                     if (nsolve > 0) {
                         const R eqr = wave_sum(aul) - beq;                         // ... and the stability row must hold
-                        if (__builtin_amdgcn_ballot_w64(off_bound) != 0 || !(fabs(eqr) <= (R)NM::eq_rel * (R(1) + fabs(beq)))) { cold = true; break; }
+                        if (__builtin_amdgcn_ballot_w64(off_bound) != 0 || !(fabs(eqr) <= (R)NM::eq_rel * (R(1) + fabs(beq)))) {
+#ifdef ISMPC_A_DIAG
+                            dg_why = 1;
+#endif
+                            cold = true; break;
+                        }
                     }
                     if (__builtin_amdgcn_ballot_w64(changed) == 0) {               // a valid pair (and, while adding, nothing violated)
                         if (!adding && extra > 0) {
@@ -828,10 +865,19 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         }
                         break;
                     }
-                    if (nsolve >= c.warm_add + c.warm_drop + c.warm_extra * (1 + c.warm_drop)) { cold = true; break; }   // budget spent: start cold
+                    if (nsolve >= c.warm_add + c.warm_drop + c.warm_extra * (1 + c.warm_drop)) {                        // budget spent: start cold
+#ifdef ISMPC_A_DIAG
+                        dg_why = 2;
+#endif
+                        cold = true; break;
+                    }
                     ++nsolve; ++iters;
                     block_solve(0ull);                                           // kinematic rows stay out of the block phase
                 }
+#ifdef ISMPC_A_DIAG
+                dg_ns += nsolve; dg_cold = cold ? dg_why : 0; dg_q0 = cold ? 0 : qz;
+#endif
+                pass_solves = nsolve; pass_cold = cold;
                 if (cold) {
 #pragma unroll
                     for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; SET_STA_(k, 0); mu[k] = R(0); pn[k] = 0; u[k] = (i <= C) ? t0 * ap[i - 1] : R(0); }
@@ -841,8 +887,12 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     WAVE_LDS_SYNC();
                 }
             }
+            if (done_opt) break;
+            if (phase == 2 && rounds_left > 0 && pass_solves > 0 && !pass_cold) { phase = 0; gi_limit = c.warm_round_adds; --rounds_left; }
 
-            if (!done_opt) for (;;) {
+            int gi_adds = 0;
+            bool gi_leave = false;                                // feasible, or failed: nothing more to do
+            for (;;) {
                 // ================= most violated inactive row =================
                 R cand = R(0), craw = R(0); int code = 0;
                 {
@@ -870,13 +920,14 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     }
                 }
                 const R vmin = wave_min(cand);
-                if (!(vmin < R(0))) break;                                        // feasible: done
+                if (!(vmin < R(0))) { gi_leave = true; break; }                   // feasible: done
                 const int wl = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(cand == vmin));
                 const int cd = rl(code, wl);
                 R sviol = rl(craw, wl);
                 const int row = cd >> 1;
                 const R sg = (cd & 1) ? R(-1) : R(1);
                 const bool isZ = row <= C;
+                if (phase == 0 && (gi_adds >= gi_limit || !isZ)) break;          // hand over to the block passes (which leave the kinematic rows alone)
                 const int kr = row - C;                                           // kinematic index when !isZ
                 // ---- the new row: border row Vp (one element per lane), footstep part mt, norm, border products dX
                 int p_k1 = 0; R p_w1 = R(1), p_pa = R(0);
@@ -1074,6 +1125,9 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         break;
                     }
                     // ============ partial step: working-set row lrow leaves ============
+#ifdef ISMPC_A_DIAG
+                    ++dg_part;
+#endif
                     if (lrow <= C) {
                         const int pnl = at_row<int, RL>(pn, lrow);
                         const int pa_ = pnl & 0xffff, pb_ = (int)((unsigned)pnl >> 16);
@@ -1106,7 +1160,11 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         --qk;
                     }
                 }
-                if (failed) break;
+                if (failed) { gi_leave = true; break; }
+                ++gi_adds;
+            }
+            if (gi_leave || phase != 0) break;
+            phase = 1;
             }
             // ---- every row, active or not, the kinematic rows and the stability row are checked once more at the point that
             // is about to be returned: a working set that pins (nearly) every variable can wear the incremental solves down
@@ -1163,6 +1221,11 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             }
         }
         // ---- LIP update (:297-322), footstep bookkeeping (:522-556), outputs: fp64 whatever the precision of the solve
+#ifdef ISMPC_A_DIAG
+        // bits 0-9 work (as in the product build) | 10-13 block solves | 14-15 why the solve started cold (1 check, 2 budget) |
+        // 16-23 ZMP rows active when Goldfarb-Idnani took over | 24-31 partial steps (rows that left inside Goldfarb-Idnani)
+        iters = (iters & 1023) | ((dg_ns & 15) << 10) | ((dg_cold & 3) << 14) | ((dg_q0 & 255) << 16) | ((dg_part & 255) << 24);
+#endif
         const bool ok = (status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) == 0;
         const double u0 = ok ? (double)rl(u[0], 0) : 0.0;
         const double f0 = ok ? cur + (double)rl(fr, 1) : cur;
