@@ -14,7 +14,7 @@ for spec in $LEGS; do
     headline)      key=headline_b65536; kern='ismpc_tick_quad<'; batch=65536; steps=40 ;;
     shard_b8192)   key=shard_b8192;     kern='ismpc_tick_quad_inline<'; batch=8192;  steps=40 ;;
     config1_b1024) key=config1_b1024;   kern='ismpc_tick_quad_inline<'; batch=1024;  steps=40 ;;
-    *)             key=$leg;            kern='ismpc_a_tick_wave<'; batch=16384; steps=5 ;;
+    *)             key=$leg;            kern='ismpc_a_tick_wave<double'; [[ $dt == f32 ]] && kern='ismpc_a_tick_wave<float'; batch=16384; steps=5 ;;   # the Monte-Carlo pre-roll runs in the OTHER precision
   esac
   [[ $dt != f64 ]] && key=${key}_$dt
   CMD="python3 $R/bench.py --only $leg --dtype $dt --no-cpu-baseline --no-extras --steps $steps --warmup 3 --min-region-ms 5"
