@@ -230,24 +230,29 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
     return d1 + ((double)q * (d2 - d1)) / (double)(ds - 1);
 }
 
-// Residency target (wavefronts per SIMD = workgroups per CU, 256 threads each): fp64 3 for two rows per lane and 2 beyond
-// (measured round 1: the 128-register budget of 4 per CU spills), fp32 4 / 3.
+// Residency target (wavefronts per SIMD = workgroups per CU, 256 threads each).  Measured with scripts/occ_sweep.sh on the
+// round-2 solver (MI355X, 16 384 pushed instances): fp32 3 for two and three rows per lane (3.3e7 vs 3.2e7 ticks/s at 4 for
+// walk C=100; 2.59e7 vs 2.45e7 at 2 for walk C=150), 2 for four rows per lane (Monte-Carlo C=200: 1.18e7 vs 9.3e6 at 3, the
+// 168-register budget spills 160 registers there); fp64 2 everywhere (walk C=100: 3.2e7 vs 2.9e7 at 3; 1 halves the rate).
 #ifndef ISMPC_A_OCC_F32_RL2      // tuning knobs (scripts/occ_sweep.sh builds variants)
-#define ISMPC_A_OCC_F32_RL2 4
+#define ISMPC_A_OCC_F32_RL2 3
 #endif
-#ifndef ISMPC_A_OCC_F32_RL34
-#define ISMPC_A_OCC_F32_RL34 3
+#ifndef ISMPC_A_OCC_F32_RL3
+#define ISMPC_A_OCC_F32_RL3 3
+#endif
+#ifndef ISMPC_A_OCC_F32_RL4
+#define ISMPC_A_OCC_F32_RL4 2
 #endif
 #ifndef ISMPC_A_OCC_F64_RL2
-#define ISMPC_A_OCC_F64_RL2 3
+#define ISMPC_A_OCC_F64_RL2 2
 #endif
 #ifndef ISMPC_A_OCC_F64_RL34
 #define ISMPC_A_OCC_F64_RL34 2
 #endif
 template <typename R, int RL, bool PI> constexpr int wave_min_blocks()
 {
-    if (PI && sizeof(R) == 8 && RL <= 2) return 2;         // 56-62 KB of LDS per workgroup: two fit a CU whatever the registers allow
-    return sizeof(R) == 4 ? (RL <= 2 ? ISMPC_A_OCC_F32_RL2 : ISMPC_A_OCC_F32_RL34) : (RL <= 2 ? ISMPC_A_OCC_F64_RL2 : ISMPC_A_OCC_F64_RL34);
+    return sizeof(R) == 4 ? (RL <= 2 ? ISMPC_A_OCC_F32_RL2 : (RL == 3 ? ISMPC_A_OCC_F32_RL3 : ISMPC_A_OCC_F32_RL4))
+                          : (RL <= 2 ? ISMPC_A_OCC_F64_RL2 : ISMPC_A_OCC_F64_RL34);
 }
 
 // RL = ZMP rows per lane (C <= 64 RL), F = footsteps in the horizon (m = 2F+1 border columns).
@@ -872,7 +877,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         cold = true; break;
                     }
                     ++nsolve; ++iters;
-                    block_solve(0ull);                                           // kinematic rows stay out of the block phase
+                    block_solve(0ull);                                           // kinematic rows stay out of the block phase (tried: the
+                                                                                 // passes adding / dropping them too changes nothing on the bench workloads)
                 }
 #ifdef ISMPC_A_DIAG
                 dg_ns += nsolve; dg_cold = cold ? dg_why : 0; dg_q0 = cold ? 0 : qz;
@@ -885,7 +891,11 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     muE = t0; qz = 0; Dd = pa2d[C]; Dee = (R)Dd;
                     for (int e = lane; e < m * m; e += 64) L.G[e] = R(0);
                     WAVE_LDS_SYNC();
+                    // a previous-tick guess that the passes could not repair: solve this QP the way a one-shot tick is solved
+                    // (a closed loop's tick is as long as its slowest QP, and a cold Goldfarb-Idnani solve is 50-100 steps)
+                    if (have_guess && c.warm_gi > 0) { phase = 0; gi_limit = c.warm_gi; }
                 }
+                have_guess = false;
             }
             if (done_opt) break;
             if (phase == 2 && rounds_left > 0 && pass_solves > 0 && !pass_cold) { phase = 0; gi_limit = c.warm_round_adds; --rounds_left; }
@@ -1198,7 +1208,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 bool bad = off_point();
                 if (bad && c.warm_add > 0) {
                     ++iters;
-                    block_solve(__builtin_amdgcn_ballot_w64(klane && kact != 0));
+                    block_solve(0ull);                                           // kinematic rows stay out of the block phase (tried: the
+                                                                                 // passes adding / dropping them too changes nothing on the bench workloads)
                     R mmax = fabs(muK);
 #pragma unroll
                     for (int k = 0; k < RL; ++k) mmax = fmax(mmax, fabs(mu[k]));

@@ -40,6 +40,18 @@ for leg in legs:
         d.copy_(d0); gen.tick_torch(d, dpush)                     # one pushed tick, then T ticks of closed loop
         t0 = time.perf_counter(); traj = gen.rollout_torch(d, T); torch.cuda.synchronize(); el = time.perf_counter() - t0
         tr = q.from_device(traj, FA.OUT_A)
+        raw = np.stack([tr["iters_x"].ravel(), tr["iters_y"].ravel()]).astype(np.int64) & 0xffffffff
+        if (raw >> 10).any():                                     # -DISMPC_A_DIAG build: statistics packed into the iteration fields
+            it = raw & 1023; act = np.stack([tr["active"].ravel() & 0xffff, (tr["active"].ravel() >> 16) & 0xffff])
+            for tick in (5, 20):
+                sl = slice(tick * B, (tick + 1) * B)
+                top = np.argsort(-it[:, sl].ravel())[:8]
+                print("tick", tick, [dict(axis=int(t // B), inst=int(t % B), work=int(it[:, sl].ravel()[t]), block_solves=int(((raw[:, sl].ravel()[t]) >> 10) & 15),
+                                          cold=int((raw[:, sl].ravel()[t] >> 14) & 3), q0=int((raw[:, sl].ravel()[t] >> 16) & 255), partial=int((raw[:, sl].ravel()[t] >> 24) & 255),
+                                          active=int(act[:, sl].ravel()[t])) for t in top], flush=True)
+            tr = tr.copy(); tr["iters_x"] = it[0].reshape(tr["iters_x"].shape); tr["iters_y"] = it[1].reshape(tr["iters_y"].shape)
         print(json.dumps({"leg": leg, "batch": B, "ticks": T, "ticks_per_s": B * T / el, "ms_per_tick": 1e3 * el / T,
-                          "status_nonzero": int((tr["status"] != 0).sum()), "iters_mean": float((tr["iters_x"] + tr["iters_y"]).mean() / 2)}), flush=True)
+                          "status_nonzero": int((tr["status"] != 0).sum()), "iters_mean": float((tr["iters_x"] + tr["iters_y"]).mean() / 2),
+                          "iters_max_per_tick": [int(v) for v in np.maximum(tr["iters_x"], tr["iters_y"]).reshape(T, B).max(1)[:12]],
+                          "iters_max_per_tick_mean": float(np.maximum(tr["iters_x"], tr["iters_y"]).reshape(T, B).max(1).mean())}), flush=True)
         gen.close()
