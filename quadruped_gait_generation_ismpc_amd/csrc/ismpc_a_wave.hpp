@@ -769,6 +769,23 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         xdrop[k] = false; anyneg = anyneg || negr[k]; pcn[k] = 0;
                     }
                     const bool wave_neg = __builtin_amdgcn_ballot_w64(anyneg) != 0;
+                    if (have_guess && nsolve == 1 && wave_neg) {
+                        // the previous tick's working set, solved as it came: if most of its multipliers are negative the set is
+                        // over-full (a horizon that was pinned end to end and is being released), every one of them would be
+                        // dropped and the passes would start from nothing -- solve this QP the one-shot way instead
+                        int nneg = 0, nall = 0;
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            nneg += __builtin_popcountll(__builtin_amdgcn_ballot_w64(negr[k]));
+                            nall += __builtin_popcountll(__builtin_amdgcn_ballot_w64(STA_(k) != 0));
+                        }
+                        if (2 * nneg > nall) {
+#ifdef ISMPC_A_DIAG
+                            dg_why = 3;
+#endif
+                            cold = true; break;
+                        }
+                    }
                     if (wave_neg && (per_end || peel > 1)) {
                         const int sprev = dpp_i<0x138, 0xf>(0, STA_(RL - 1)), snext = dpp_i<0x130, 0xf>(0, STA_(0));
                         int lst = 0, len_ = 1 << 30;                            // this lane's last run start / first run end
