@@ -815,7 +815,10 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                             const int i = lane * RL + k + 1;
                             if (STA_(k) != 0 && runlo[k] >= 1 && runhi[k] <= C && runlo[k] != runhi[k]) {
                                 const int dl = (int)L.sv[runlo[k] - 1], dh = (int)L.sv[runhi[k] - 1];      // 0: that end is not negative
-                                if (i - runlo[k] < dl || runhi[k] - i < dh) xdrop[k] = true;
+                                // ... but never the row at the other end: a run shrinks to one row, and that row leaves only on its
+                                // own multiplier.  (Cutting a two-row touching point away altogether un-pins the trajectory there,
+                                // every other multiplier turns negative at once and the next pass starts from nothing.)
+                                if ((i - runlo[k] < dl && i < runhi[k]) || (runhi[k] - i < dh && i > runlo[k])) xdrop[k] = true;
                                 if (per_end) {                                                            // the row that becomes the new end
                                     if (dl > 0 && i - runlo[k] == dl) pcn[k] = min(32 - __builtin_clz(dl), 6);
                                     if (dh > 0 && runhi[k] - i == dh) pcn[k] = max(pcn[k], min(32 - __builtin_clz(dh), 6));

@@ -67,7 +67,7 @@ def picture(W, C):
     return "".join(s)
 
 
-def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol=6, log=None, damp=None, perend=False, cap=64, gi_first=0, thin=False, rounds=0, round_adds=12, guard=False):
+def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol=6, log=None, damp=None, perend=False, cap=64, gi_first=0, thin=False, rounds=0, round_adds=12, guard=False, keep1=False):
     """Returns (block solves, GI steps, |W| at GI start, x).  Variants:
     peel_drop / peel_add: geometric peeling in drop-only / adding passes; readd: re-entries into an adding pass when a valid pair
     still has >= min_viol violated rows; damp: None | 'ends' (an adding pass adds, of each run of violated rows, ...)"""
@@ -79,13 +79,13 @@ def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol
         if log is not None: log.append(f"G  |W|={len(W):3d} steps={gi0:2d}  " + picture(W, C))
         if done: return 0, gi0, len(W), x
     for rnd in range(rounds):
-        ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard)
+        ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1)
         ns_tot += ns
         x, W, mu, st, done = gi_some(Q, W, x, mu, round_adds)
         gi0 += st
         if log is not None: log.append(f"G  |W|={len(W):3d} steps={st:2d}  " + picture(W, C))
         if done: return ns_tot, gi0, len(W), x
-    ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard)
+    ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1)
     ns_tot += ns
     q0 = len(W)
     x, W2, steps = gi_from(H, g, E, b, N, lo, hi, W, x, mu)
@@ -93,7 +93,7 @@ def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol
     return ns_tot, steps + gi0, q0, x
 
 
-def block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard):
+def block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1):
     H, g, E, b, N, lo, hi = Q
     peel = 1; nsolve = 0; force_add = False; extra = readd; pc = {}
     newrows = set(); stop_adding = False
@@ -114,11 +114,11 @@ def block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol
                 if l == h: continue
                 if l in neg:
                     d = pc.get(l, 1)
-                    for r in range(l, min(h, l + d - 1) + 1): dropset.add(r)
+                    for r in range(l, min(h - 1 if keep1 else h, l + d - 1) + 1): dropset.add(r)
                     if l + d <= h: pcn[l + d] = min(2 * d, cap)
                 if h in neg:
                     d = pc.get(h, 1)
-                    for r in range(max(l, h - d + 1), h + 1): dropset.add(r)
+                    for r in range(max(l + 1 if keep1 else l, h - d + 1), h + 1): dropset.add(r)
                     if h - d >= l: pcn[h - d] = min(2 * d, cap)
             pc = pcn
         elif peel > 1 and neg and (peel_add if adding else peel_drop):
@@ -196,6 +196,8 @@ VARIANTS = {
     "new_r2": dict(perend=True, gi_first=3, add=6, drop=12, rounds=2, round_adds=8),
     "new_r2_4": dict(perend=True, gi_first=3, add=6, drop=12, rounds=2, round_adds=4),
     "new_r3_4": dict(perend=True, gi_first=3, add=4, drop=12, rounds=3, round_adds=4),
+    "keep1": dict(perend=True, gi_first=3, add=6, drop=12, rounds=2, round_adds=8, keep1=True),
+    "base": dict(perend=True, gi_first=3, add=6, drop=12, rounds=2, round_adds=8),
     "guard": dict(perend=True, gi_first=3, add=6, drop=12, guard=True),
     "thin": dict(perend=True, gi_first=3, add=6, drop=12, thin=True),
     "thin_gi1": dict(perend=True, gi_first=1, add=6, drop=12, thin=True),
