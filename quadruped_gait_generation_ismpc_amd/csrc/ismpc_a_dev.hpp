@@ -15,7 +15,7 @@ struct DevA {
     int warm_add, warm_drop, warm_extra, warm_min_viol; // block warm start of the wave kernel: passes that add + drop rows, passes that only drop,
                                          // re-entries into adding passes, violated rows that make a re-entry worth it
     int warm_gi, warm_peel_end;          // Goldfarb-Idnani row additions BEFORE the block passes (0: passes start from the equality-only
-                                         // point); 1: every run end keeps its own peel length, 0: one length per QP
+                                         // point); 1: a negative run end takes more than itself with it (0: only itself)
     int warm_rounds, warm_round_adds;    // after the passes: up to warm_rounds times, warm_round_adds more Goldfarb-Idnani additions and, if
                                          // rows are still violated then, the passes again (a collapsed warm start recovers in one round)
     double dt, eta, w, Qf, disp_forw, disp_forw_dummy, disp_L, aa, wP, sumw;

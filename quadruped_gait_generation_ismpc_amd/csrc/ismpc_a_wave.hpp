@@ -180,6 +180,12 @@ template <typename R, int NS> __device__ __forceinline__ void wave_fold_sums(con
     wave_fold_sums_from<R, NS, 5, 0>(acc, out, lane);
 }
 
+// a flag carried in the last mantissa bit of a value (one ulp of the value is given up)
+__device__ __forceinline__ float with_flag(float v, bool f) { return __int_as_float((__float_as_int(v) & ~1) | (f ? 1 : 0)); }
+__device__ __forceinline__ double with_flag(double v, bool f) { return __longlong_as_double((__double_as_longlong(v) & ~1ll) | (f ? 1ll : 0ll)); }
+__device__ __forceinline__ bool flag_of(float v) { return (__float_as_int(v) & 1) != 0; }
+__device__ __forceinline__ bool flag_of(double v) { return (__double_as_longlong(v) & 1ll) != 0; }
+
 // ---- per-wavefront LDS.  Small vectors (length m = 2F+1 or F+2) are kept ONE ELEMENT PER LANE in registers and mirrored here
 // when other lanes need them by index; nothing of size "working set" is stored anywhere.
 template <typename R, int F> struct WaveLds {
@@ -359,7 +365,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         }
 
         // ---- per-row data: lane owns ZMP rows lane*RL+1 .. lane*RL+RL (row i = sample i, u index i-1).
-        // ks = first mapped footstep (bits 0-3) | row state + 1 (bits 4-5: 0 upper active, 1 free, 2 lower active) | peel (bits 6-8);
+        // ks = first mapped footstep (bits 0-3) | row state + 1 (bits 4-5: 0 upper active, 1 free, 2 lower active);
         // pn = previous active row (bits 0-15) | next active row (bits 16-31), kept for every row, active or not
         R u[RL], w1[RL], mu[RL];
         float inrm[RL];
@@ -367,7 +373,6 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #define K1_(k_)  (ks[k_] & 15)
 #define STA_(k_) (((ks[k_] >> 4) & 3) - 1)
 #define SET_STA_(k_, s_) (ks[k_] = (ks[k_] & 15) | (((s_) + 1) << 4))
-#define PC_(k_) ((ks[k_] >> 6) & 7)                     /* bits 6-8: log2 of the peel length of a run end (block passes only; SET_STA_ clears it) */
 #define PRV_(k_) (pn[k_] & 0xffff)
 #define NXT_(k_) ((int)((unsigned)pn[k_] >> 16))
 #define SET_PRV_(k_, p_) (pn[k_] = (pn[k_] & ~0xffff) | (p_))
@@ -732,7 +737,6 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 phase = 2;
                 bool cold = false, force_add = false;
                 int extra = c.warm_extra, nsolve = 0;
-                int peel = 1;
                 // the previous tick's working set, moved down by one row (the horizon advanced by one sample); any guess is
                 // safe, the passes validate it
                 int guess[RL];
@@ -756,17 +760,19 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     row_values(vv);
                     // ---- rows that leave: multiplier not positive (while adding) / negative (drop-only passes).  Such a row
                     // usually sits at the end of a run of consecutive rows on the same bound, and the run has to shrink by
-                    // more than one row ("peeling"): an end that is negative again one pass after it was cut has twice as many
-                    // rows taken off (each run end keeps its own length, on the row that becomes the new end; with
-                    // c.warm_peel_end = 0 one length per QP, doubled while any row is negative).  Taking off too many costs
-                    // little while rows are still being added: they come back as violated rows.
+                    // more than that one row.  How far: a multiplier at row i acts on u_j, j <= i, exactly like one at any later
+                    // row, so the multipliers of the rows cut off a run's end, lumped onto the new end row, leave the earlier
+                    // horizon as it is -- and the new end must come out positive.  A negative end therefore takes with it the
+                    // rows whose multipliers, summed from that end, are still <= 0 (scripts/proto_passes.py: 15 % less work than
+                    // doubling the cut from pass to pass, worst QP 22 -> 11-18 units, no state between passes).  Never the row
+                    // at the other end: a run shrinks to one row, which leaves only on its own multiplier (cutting a two-row
+                    // touching point away un-pins the trajectory there, every other multiplier turns negative at once and the
+                    // next pass starts from nothing).
                     bool xdrop[RL], negr[RL], anyneg = false;
-                    int pcn[RL];
-                    const bool per_end = c.warm_peel_end != 0;
 #pragma unroll
                     for (int k = 0; k < RL; ++k) {
                         negr[k] = STA_(k) != 0 && (adding ? !(mu[k] > R(0)) : (mu[k] < R(0)));
-                        xdrop[k] = false; anyneg = anyneg || negr[k]; pcn[k] = 0;
+                        xdrop[k] = false; anyneg = anyneg || negr[k];
                     }
                     const bool wave_neg = __builtin_amdgcn_ballot_w64(anyneg) != 0;
                     if (have_guess && nsolve == 1 && wave_neg) {
@@ -786,10 +792,13 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                             cold = true; break;
                         }
                     }
-                    if (wave_neg && (per_end || peel > 1)) {
+                    if (wave_neg && c.warm_peel_end != 0) {
                         const int sprev = dpp_i<0x138, 0xf>(0, STA_(RL - 1)), snext = dpp_i<0x130, 0xf>(0, STA_(0));
                         int lst = 0, len_ = 1 << 30;                            // this lane's last run start / first run end
                         bool isst[RL], isen[RL];
+                        // inclusive prefix sums P of the (signed) multipliers over the active rows, each with its row's verdict in the
+                        // last mantissa bit: the sum over any stretch of a run is a difference of two of them
+                        R Pk[RL], lc = R(0);
 #pragma unroll
                         for (int k = 0; k < RL; ++k) {
                             const int i = lane * RL + k + 1;
@@ -798,8 +807,12 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                             isst[k] = sk != 0 && sb != sk; isen[k] = sk != 0 && sa != sk;
                             if (isst[k]) lst = i;
                             if (isen[k]) len_ = min(len_, i);
-                            if (i <= C) L.sv[i - 1] = negr[k] ? (R)(per_end ? (1 << PC_(k)) : peel) : R(0);   // rows to take off if this is a run end
+                            if (sk != 0) lc += mu[k];
+                            Pk[k] = lc;
                         }
+                        const R bs = wave_scan_up(lc) - lc;
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; Pk[k] += bs; if (i <= C) L.sv[i - 1] = with_flag(Pk[k], negr[k]); }
                         int runlo[RL], runhi[RL];
                         int run = dpp_i<0x138, 0xf>(0, wave_scan_max_i(lst));
 #pragma unroll
@@ -814,20 +827,14 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         for (int k = 0; k < RL; ++k) {
                             const int i = lane * RL + k + 1;
                             if (STA_(k) != 0 && runlo[k] >= 1 && runhi[k] <= C && runlo[k] != runhi[k]) {
-                                const int dl = (int)L.sv[runlo[k] - 1], dh = (int)L.sv[runhi[k] - 1];      // 0: that end is not negative
-                                // ... but never the row at the other end: a run shrinks to one row, and that row leaves only on its
-                                // own multiplier.  (Cutting a two-row touching point away altogether un-pins the trajectory there,
-                                // every other multiplier turns negative at once and the next pass starts from nothing.)
-                                if ((i - runlo[k] < dl && i < runhi[k]) || (runhi[k] - i < dh && i > runlo[k])) xdrop[k] = true;
-                                if (per_end) {                                                            // the row that becomes the new end
-                                    if (dl > 0 && i - runlo[k] == dl) pcn[k] = min(32 - __builtin_clz(dl), 6);
-                                    if (dh > 0 && runhi[k] - i == dh) pcn[k] = max(pcn[k], min(32 - __builtin_clz(dh), 6));
-                                }
+                                const R eh = L.sv[runhi[k] - 1], el = L.sv[runlo[k] - 1];
+                                const R pb = runlo[k] > 1 ? L.sv[runlo[k] - 2] : R(0);                      // P just before the run
+                                if (flag_of(eh) && i > runlo[k] && !((eh - Pk[k]) + mu[k] > R(0))) xdrop[k] = true;
+                                if (flag_of(el) && i < runhi[k] && !(Pk[k] - pb > R(0))) xdrop[k] = true;
                             }
                         }
                         WAVE_LDS_SYNC();
                     }
-                    peel = wave_neg ? min(2 * peel, 64) : 1;
                     bool changed = false, off_bound = false;
                     R aul = R(0);
 #pragma unroll
@@ -850,7 +857,6 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                             }
                             changed = changed || ns != os;
                             SET_STA_(k, ns);
-                            ks[k] |= pcn[k] << 6;
                         }
                     }
                     if (nsolve > 0) {

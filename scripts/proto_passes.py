@@ -67,7 +67,7 @@ def picture(W, C):
     return "".join(s)
 
 
-def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol=6, log=None, damp=None, perend=False, cap=64, gi_first=0, thin=False, rounds=0, round_adds=12, guard=False, keep1=False):
+def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol=6, log=None, damp=None, perend=False, cap=64, gi_first=0, thin=False, rounds=0, round_adds=12, guard=False, keep1=False, lump=False):
     """Returns (block solves, GI steps, |W| at GI start, x).  Variants:
     peel_drop / peel_add: geometric peeling in drop-only / adding passes; readd: re-entries into an adding pass when a valid pair
     still has >= min_viol violated rows; damp: None | 'ends' (an adding pass adds, of each run of violated rows, ...)"""
@@ -79,13 +79,13 @@ def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol
         if log is not None: log.append(f"G  |W|={len(W):3d} steps={gi0:2d}  " + picture(W, C))
         if done: return 0, gi0, len(W), x
     for rnd in range(rounds):
-        ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1)
+        ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1, lump)
         ns_tot += ns
         x, W, mu, st, done = gi_some(Q, W, x, mu, round_adds)
         gi0 += st
         if log is not None: log.append(f"G  |W|={len(W):3d} steps={st:2d}  " + picture(W, C))
         if done: return ns_tot, gi0, len(W), x
-    ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1)
+    ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1, lump)
     ns_tot += ns
     q0 = len(W)
     x, W2, steps = gi_from(H, g, E, b, N, lo, hi, W, x, mu)
@@ -93,7 +93,7 @@ def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol
     return ns_tot, steps + gi0, q0, x
 
 
-def block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1):
+def block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1, lump):
     H, g, E, b, N, lo, hi = Q
     peel = 1; nsolve = 0; force_add = False; extra = readd; pc = {}
     newrows = set(); stop_adding = False
@@ -106,7 +106,24 @@ def block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol
         tol = 1e-11 * (np.abs(cv) + np.maximum(np.abs(lo), np.abs(hi))) + 1e-13
         neg = {r for r in W if r < C and (mu[r] <= 0 if adding else mu[r] < 0)}
         dropset = set(neg)
-        if perend:
+        if lump:
+            # a negative run end: the rows it takes with it are those whose multipliers, summed from that end, stay <= 0
+            # (a multiplier at row i acts on u_j, j <= i, exactly like one at any later row: lumping the cut rows' multipliers
+            # onto the new end row leaves the earlier part of the horizon as it is, and the new end must come out positive)
+            rn = runs_of(W, C)
+            for (l, h) in set(rn.values()):
+                if l == h: continue
+                if h in neg:
+                    c = 0.0
+                    for r in range(h, l, -1):
+                        c += mu[r]
+                        if c <= 0: dropset.add(r)
+                if l in neg:
+                    c = 0.0
+                    for r in range(l, h):
+                        c += mu[r]
+                        if c <= 0: dropset.add(r)
+        elif perend:
             # every run end keeps its own peel length: an end that is negative again one pass after it was cut doubles its cut
             pcn = {}
             rn = runs_of(W, C)
@@ -198,6 +215,13 @@ VARIANTS = {
     "new_r3_4": dict(perend=True, gi_first=3, add=4, drop=12, rounds=3, round_adds=4),
     "keep1": dict(perend=True, gi_first=3, add=6, drop=12, rounds=2, round_adds=8, keep1=True),
     "base": dict(perend=True, gi_first=3, add=6, drop=12, rounds=2, round_adds=8),
+    "lump": dict(perend=True, gi_first=3, add=6, drop=12, rounds=2, round_adds=8, lump=True),
+    "lump_gi0": dict(perend=True, gi_first=0, add=6, drop=12, rounds=2, round_adds=8, lump=True),
+    "lump_gi1": dict(perend=True, gi_first=1, add=6, drop=12, rounds=2, round_adds=8, lump=True),
+    "lump_gi2": dict(perend=True, gi_first=2, add=6, drop=12, rounds=2, round_adds=8, lump=True),
+    "lump_gi4": dict(perend=True, gi_first=4, add=6, drop=12, rounds=2, round_adds=8, lump=True),
+    "lump_gi2_r4": dict(perend=True, gi_first=2, add=6, drop=12, rounds=2, round_adds=4, lump=True),
+    "lump_43": dict(perend=True, gi_first=3, add=4, drop=6, rounds=2, round_adds=8, lump=True),
     "guard": dict(perend=True, gi_first=3, add=6, drop=12, guard=True),
     "thin": dict(perend=True, gi_first=3, add=6, drop=12, thin=True),
     "thin_gi1": dict(perend=True, gi_first=1, add=6, drop=12, thin=True),

@@ -318,13 +318,13 @@ def test_per_instance_invalid_records_are_flagged(FA):
     assert np.abs(ob["u0"][0] - o["u0"][0]).max() <= 1e-9 and np.abs(ob["f0"][0] - o["f0"][0]).max() <= 1e-10
 
 
-@pytest.mark.parametrize("route", ["default", "passes_only", "global_peel"])
+@pytest.mark.parametrize("route", ["default", "passes_only", "no_peel"])
 @pytest.mark.parametrize("name", ["walk_C100", "walk_C150", "trot_C160"])
 def test_block_warm_start_equals_cold_start(FA, name, route, monkeypatch):
     """The block warm start (a few exact Goldfarb-Idnani steps, primal-dual passes, rounds of both) only changes the route,
     never the optimum: 4 096 perturbed instances per workload, pushes from mild to far beyond what the ZMP band can absorb
     (infeasible QPs included), warm-started handle against a handle created with ISMPC_A_WARM=0.  Routes: the default; the
-    passes alone from the equality-only point (no exact steps first, no rounds); one peel length per QP."""
+    passes alone from the equality-only point (no exact steps first, no rounds); negative run ends leave alone."""
     import torch
     z = np.load(os.path.join(GOLDEN, f"prerollA_{name}.npz"))
     tab = z["state"].view(FA.STATE_A).reshape(-1)
@@ -333,7 +333,7 @@ def test_block_warm_start_equals_cold_start(FA, name, route, monkeypatch):
     p = FA.default_params(kind, C=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
     monkeypatch.delenv("ISMPC_A_WARM", raising=False)
     if route == "passes_only": monkeypatch.setenv("ISMPC_A_WARM", "4,6,0,6,0,1,0,8")
-    if route == "global_peel": monkeypatch.setenv("ISMPC_A_WARM", "6,12,0,6,3,0,2,8")
+    if route == "no_peel": monkeypatch.setenv("ISMPC_A_WARM", "6,12,0,6,3,0,2,8")
     warm = FA.GaitGenerator(p, ce)
     monkeypatch.setenv("ISMPC_A_WARM", "0")
     cold = FA.GaitGenerator(p, ce)
