@@ -52,7 +52,10 @@ def build(force=False, verbose=False, out=None, flags=None):
     if force or _stale(target, deps, flags):
         objdir = os.path.join(ROOT, "build", "obj", os.path.basename(target))
         os.makedirs(objdir, exist_ok=True)
-        common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include")] + flags.split()
+        # -fno-slp-vectorize: the SLP vectoriser pairs fp32 values into 64-bit register tuples (v_pk_*); in the Formulation A wave
+        # kernels that costs far more registers than it saves instructions (<float,3,4,false>: 60 spilled VGPRs with it, 7 without;
+        # <float,4,6,true>: 40 -> 0; measured +2-4 % ticks/s, +20 % on trot C=160 fp32)
+        common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include")] + flags.split()
         procs = []
         for src in hip_src:
             obj = os.path.join(objdir, os.path.basename(src) + ".o")

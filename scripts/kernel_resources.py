@@ -13,7 +13,7 @@ if "--md" in args:
 rows = []
 for src in ("ismpc_hip.hip", "ismpc_a_hip.hip", "ismpc_a_wave_rl2.hip", "ismpc_a_wave_rl3.hip", "ismpc_a_wave_rl4.hip"):
     with tempfile.TemporaryDirectory() as td:
-        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
                             "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", os.path.join(td, "x.o")]
                            + os.environ.get("ISMPC_HIPCC_FLAGS", "").split(), capture_output=True, text=True)
     if r.returncode != 0:
@@ -39,5 +39,5 @@ txt = "\n".join(out)
 print(txt)
 if md:
     with open(md, "w") as f:
-        f.write("# Kernel resources (hipcc --offload-arch=gfx950 -O3, -Rpass-analysis=kernel-resource-usage)\n\n"
+        f.write("# Kernel resources (hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize, -Rpass-analysis=kernel-resource-usage)\n\n"
                 "Regenerate: `python scripts/kernel_resources.py --md " + os.path.relpath(md, ROOT) + "`\n\n" + txt + "\n")
