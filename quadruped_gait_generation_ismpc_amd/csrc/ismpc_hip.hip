@@ -1705,6 +1705,8 @@ struct ismpc_handle {
     std::vector<void*> dev_allocs;
     // staging for the host-pointer entry point
     ismpc_tick_in* st_in = nullptr; ismpc_tick_out* st_out = nullptr; int st_cap = 0;
+    ismpc_tick_in* pin_in = nullptr; ismpc_tick_out* pin_out = nullptr;   // host-mapped staging for small batches (PIN_BATCH records)
+    bool pin_off = false;
     hipStream_t own_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false; bool timed_pending = false; double last_ms = 0.0;
@@ -1957,6 +1959,8 @@ void ismpc_destroy(ismpc_handle* h)
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->st_in) (void)hipFree(h->st_in);
     if (h->st_out) (void)hipFree(h->st_out);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->zmark) (void)hipFree(h->zmark);
     if (h->zstop) (void)hipFree(h->zstop);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1983,6 +1987,33 @@ int ismpc_solve_batch(ismpc_handle* h, int batch, const ismpc_tick_in* in_host, 
     if (!h || batch < 0 || (batch > 0 && (!in_host || !out_host))) return fail(ISMPC_E_INVALID, "bad argument");
     if (batch == 0) return ISMPC_OK;
     ON_DEVICE(h);
+    // A batch of a few instances (the reference's own call: one MPCSolver::solve per control tick) is all latency: the kernel
+    // reads its records from, and writes them to, host memory mapped into the device's address space -- two memcpy submissions
+    // less than the staged path below.  ISMPC_PINNED=0 switches it off.
+    constexpr int PIN_BATCH = 64;
+    if (batch <= PIN_BATCH && !h->pin_off) {
+        if (!h->pin_in) {
+            if (const char* e = std::getenv("ISMPC_PINNED")) h->pin_off = std::atoi(e) == 0;
+            if (!h->pin_off) {
+                if (hipHostMalloc((void**)&h->pin_in, sizeof(ismpc_tick_in) * PIN_BATCH, hipHostMallocMapped) != hipSuccess ||
+                    hipHostMalloc((void**)&h->pin_out, sizeof(ismpc_tick_out) * PIN_BATCH, hipHostMallocMapped) != hipSuccess) {
+                    (void)hipGetLastError(); h->pin_off = true;
+                    if (h->pin_in) { (void)hipHostFree(h->pin_in); h->pin_in = nullptr; }
+                }
+            }
+        }
+        if (!h->pin_off) {
+            ismpc_tick_in* din = nullptr; ismpc_tick_out* dout = nullptr;
+            HIP_TRY(hipHostGetDevicePointer((void**)&din, h->pin_in, 0));
+            HIP_TRY(hipHostGetDevicePointer((void**)&dout, h->pin_out, 0));
+            std::memcpy(h->pin_in, in_host, sizeof(ismpc_tick_in) * (size_t)batch);
+            const int rc = ismpc_solve_batch_device(h, batch, din, dout, nullptr, h->own_stream);
+            if (rc != ISMPC_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(h->own_stream));
+            std::memcpy(out_host, h->pin_out, sizeof(ismpc_tick_out) * (size_t)batch);
+            return ISMPC_OK;
+        }
+    }
     if (batch > h->st_cap) {
         if (h->st_in) (void)hipFree(h->st_in);
         if (h->st_out) (void)hipFree(h->st_out);

@@ -39,7 +39,7 @@ for t in range(tick + 1):
         x, mu = solve_on(H, g, E, b, N, lo, hi, guess)
         log = []
         for rnd in range(3):
-            ns, W, x, mu = block_passes(Q, C, dict(guess) if rnd == 0 else W, x, mu, 6, 12, True, True, 0, 6, log, True, 64, False, False, bool(int(os.environ.get('KEEP1', '0'))), bool(int(os.environ.get('LUMP', '0'))))
+            ns, W, x, mu = block_passes(Q, C, dict(guess) if rnd == 0 else W, x, mu, 6, 12, True, True, 0, 6, log, True, 64, False, False, bool(int(os.environ.get('KEEP1', '0'))), bool(int(os.environ.get('LUMP', '0'))), bool(int(os.environ.get('SKIPDROP', '0'))))
             x, W, mu, st, done = gi_some(Q, W, x, mu, 8 if rnd < 2 else 10 ** 6)
             log.append(f"G  |W|={len(W):3d} steps={st:2d}  " + picture(W, C) + ("  done" if done else ""))
             if done: break

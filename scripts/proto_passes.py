@@ -67,7 +67,7 @@ def picture(W, C):
     return "".join(s)
 
 
-def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol=6, log=None, damp=None, perend=False, cap=64, gi_first=0, thin=False, rounds=0, round_adds=12, guard=False, keep1=False, lump=False):
+def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol=6, log=None, damp=None, perend=False, cap=64, gi_first=0, thin=False, rounds=0, round_adds=12, guard=False, keep1=False, lump=False, skipdrop=False):
     """Returns (block solves, GI steps, |W| at GI start, x).  Variants:
     peel_drop / peel_add: geometric peeling in drop-only / adding passes; readd: re-entries into an adding pass when a valid pair
     still has >= min_viol violated rows; damp: None | 'ends' (an adding pass adds, of each run of violated rows, ...)"""
@@ -79,13 +79,13 @@ def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol
         if log is not None: log.append(f"G  |W|={len(W):3d} steps={gi0:2d}  " + picture(W, C))
         if done: return 0, gi0, len(W), x
     for rnd in range(rounds):
-        ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1, lump)
+        ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1, lump, skipdrop)
         ns_tot += ns
         x, W, mu, st, done = gi_some(Q, W, x, mu, round_adds)
         gi0 += st
         if log is not None: log.append(f"G  |W|={len(W):3d} steps={st:2d}  " + picture(W, C))
         if done: return ns_tot, gi0, len(W), x
-    ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1, lump)
+    ns, W, x, mu = block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1, lump, skipdrop)
     ns_tot += ns
     q0 = len(W)
     x, W2, steps = gi_from(H, g, E, b, N, lo, hi, W, x, mu)
@@ -93,7 +93,7 @@ def passes(Q, C, add=4, drop=6, peel_drop=True, peel_add=True, readd=0, min_viol
     return ns_tot, steps + gi0, q0, x
 
 
-def block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1, lump):
+def block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol, log, perend, cap, thin, guard, keep1, lump, skipdrop):
     H, g, E, b, N, lo, hi = Q
     peel = 1; nsolve = 0; force_add = False; extra = readd; pc = {}
     newrows = set(); stop_adding = False
@@ -106,7 +106,11 @@ def block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol
         tol = 1e-11 * (np.abs(cv) + np.maximum(np.abs(lo), np.abs(hi))) + 1e-13
         neg = {r for r in W if r < C and (mu[r] <= 0 if adding else mu[r] < 0)}
         dropset = set(neg)
-        if lump:
+        collapse = skipdrop and nsolve > 0 and 2 * len(neg) > len(W)
+        if collapse:
+            # most multipliers negative at once: the last cut took a pin away.  Drop nothing, let the violated rows back in
+            dropset = set(); adding = True
+        elif lump:
             # a negative run end: the rows it takes with it are those whose multipliers, summed from that end, stay <= 0
             # (a multiplier at row i acts on u_j, j <= i, exactly like one at any later row: lumping the cut rows' multipliers
             # onto the new end row leaves the earlier part of the horizon as it is, and the new end must come out positive)
@@ -179,6 +183,8 @@ def block_passes(Q, C, W, x, mu, add, drop, peel_drop, peel_add, readd, min_viol
                 if int(r) not in W: new[int(r)] = +1
             for r in np.nonzero(cv[:C] > (hi + tol)[:C])[0]:
                 if int(r) not in W: new[int(r)] = -1
+        if collapse and new == W:                     # nothing came back: the negatives have to go after all
+            new = {r: s for r, s in W.items() if r not in neg}
         newrows = set(new) - set(W)
         if log is not None: log.append(("A" if adding else "D") + f"{p:2d} |W|={len(W):3d} neg={len(neg):3d} " + picture(W, C))
         if new == W:
@@ -221,6 +227,8 @@ VARIANTS = {
     "lump_gi2": dict(perend=True, gi_first=2, add=6, drop=12, rounds=2, round_adds=8, lump=True),
     "lump_gi4": dict(perend=True, gi_first=4, add=6, drop=12, rounds=2, round_adds=8, lump=True),
     "lump_gi2_r4": dict(perend=True, gi_first=2, add=6, drop=12, rounds=2, round_adds=4, lump=True),
+    "lump_sd": dict(perend=True, gi_first=2, add=6, drop=12, rounds=2, round_adds=8, lump=True, skipdrop=True),
+    "lump_g2": dict(perend=True, gi_first=2, add=6, drop=12, rounds=2, round_adds=8, lump=True),
     "lump_43": dict(perend=True, gi_first=3, add=4, drop=6, rounds=2, round_adds=8, lump=True),
     "guard": dict(perend=True, gi_first=3, add=6, drop=12, guard=True),
     "thin": dict(perend=True, gi_first=3, add=6, drop=12, thin=True),
