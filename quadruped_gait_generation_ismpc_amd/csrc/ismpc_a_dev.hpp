@@ -35,6 +35,7 @@ struct WaveLaunch {
     int batch; int* work_counter; unsigned long long* hist; int hist_load;
     int precision; int cus; int* occ_cache;       // occ_cache: per handle, [F - 3][precision x per-instance], 0 = not queried yet
     const int* order; const int* count_ptr;       // NULL, or the instances of this launch (device list + device count): see tick_launch
+    int claim_chunk;                              // QPs a wavefront takes from the work counter per atomic
     hipStream_t stream;
 };
 

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(WG, (wave_min_blocks<R, RL, PI>()))
 void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
                        const ismpc_a_inst* __restrict__ ipar, const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch,
                        int* __restrict__ work_counter, unsigned long long* __restrict__ hist, int hist_load,
-                       const int* __restrict__ order, const int* __restrict__ count_ptr)
+                       const int* __restrict__ order, const int* __restrict__ count_ptr, const int claim_chunk_)
 {
     using NM = Num<R>;
     const DevA& c = *cp;                                   // handle constants, read from memory where they are used (by value they would
@@ -298,11 +298,17 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     const double* pad = PI ? pad_pi[PI ? wv : 0] : pad_s;
     const double* pa2d = PI ? pa2d_pi[PI ? wv : 0] : pa2d_s;
 
-    // QPs are claimed one at a time from a global counter: iteration counts differ a lot between instances
+    // QPs are claimed from a global counter, claim_chunk at a time: iteration counts differ a lot between instances, but one
+    // device-wide atomic per QP is a floor of its own (every wavefront of the chip on one address)
+    int claim_cur = 0, claim_end = 0;
+    const int claim_chunk = max(claim_chunk_, 1);
     for (;;) {
-        int claimed = 0;
-        if (lane == 0) claimed = atomicAdd(work_counter, 1);
-        const int work = __builtin_amdgcn_readfirstlane(claimed);
+        if (claim_cur == claim_end) {
+            int claimed = 0;
+            if (lane == 0) claimed = atomicAdd(work_counter, claim_chunk);
+            claim_cur = __builtin_amdgcn_readfirstlane(claimed); claim_end = claim_cur + claim_chunk;
+        }
+        const int work = claim_cur++;
         // instances of this launch: all `batch` of them, or the `*count_ptr` listed in `order` (per-instance parameters: the
         // host sorts the instances by their footstep count and runs each group through the kernel of that shape)
         if (work >= 2 * (count_ptr ? *count_ptr : batch)) break;
@@ -1321,7 +1327,7 @@ inline int launch_one(const WaveLaunch& L, hipError_t* err)
     }
     const int grid = std::min((2 * L.batch + 3) / 4, L.cus * occ);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), 0, L.stream, L.c_dev, L.prev, L.state, L.inst, L.push, L.out, L.batch, L.work_counter, L.hist, L.hist_load,
-                       L.order, L.count_ptr);
+                       L.order, L.count_ptr, L.claim_chunk);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = e; return -2; }
     return 0;
