@@ -36,6 +36,7 @@ struct WaveLaunch {
     int precision; int cus; int* occ_cache;       // occ_cache: per handle, [F - 3][precision x per-instance], 0 = not queried yet
     const int* order; const int* count_ptr;       // NULL, or the instances of this launch (device list + device count): see tick_launch
     int claim_chunk;                              // QPs a wavefront takes from the work counter per atomic
+    int static_q;                                 // sixteenths of the launch's QPs that are dealt out statically (no atomics) first
     hipStream_t stream;
 };
 

@@ -683,6 +683,8 @@ struct ismpc_a_handle {
     int* work_counter = nullptr;
     unsigned long long* hist = nullptr; int hist_cap = 0;   // per-QP working set of the previous tick (closed-loop first guess)
     int claim_chunk = 0;                                  // 0: by shape (tick_launch), else ISMPC_A_CLAIM
+    int static_q = 8;                                     // sixteenths of a launch dealt out without atomics (ISMPC_A_STATIC; scripts/claim_sweep.sh:
+                                                          // half is +2-12 % on every bench leg, three quarters starts to cost balance)
     bool hist_ticks = false, hist_valid = false;           // use it in plain tick calls too / it holds the previous tick of this batch
     int hist_batch = 0; bool hist_off = false;            // ISMPC_A_HISTORY=0: never (A/B)
     std::vector<void*> allocs;
@@ -819,7 +821,8 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     // ISMPC_A_WARM=add,drop,extra,min_viol,gi_first,peel,rounds,round_adds overrides; ISMPC_A_WARM=0 starts every QP cold
     c.warm_add = 6; c.warm_drop = 12; c.warm_extra = 0; c.warm_min_viol = 6; c.warm_gi = 2; c.warm_peel_end = 1;
     c.warm_rounds = 2; c.warm_round_adds = 8;
-    if (const char* e = std::getenv("ISMPC_A_CLAIM")) h->claim_chunk = std::max(1, std::min(std::atoi(e), 64));
+    if (const char* e = std::getenv("ISMPC_A_STATIC")) h->static_q = std::max(0, std::min(std::atoi(e), 16));
+    if (const char* e = std::getenv("ISMPC_A_CLAIM")) h->claim_chunk = std::max(0, std::min(std::atoi(e), 64));   // 0: by shape
     if (const char* e = std::getenv("ISMPC_A_WARM")) {
         int a_ = 0, d_ = 0, x_ = 0, v_ = 0, g_ = 0, pe_ = 0, r_ = 0, ra_ = 0;
         const int got = std::sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &a_, &d_, &x_, &v_, &g_, &pe_, &r_, &ra_);
@@ -999,9 +1002,10 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
         HIP_TRY_A(hipMemsetAsync(h->work_counter, 0, sizeof(int), s));
         if (h->c_dirty) { HIP_TRY_A(hipMemcpyAsync(h->c_dev, &h->c, sizeof(DevA), hipMemcpyHostToDevice, s)); h->c_dirty = false; }
         ismpc_a::WaveLaunch WL{h->c_dev, h->c.F, h->prev, state_dev, inst_dev, push_dev, out_dev, batch, h->work_counter, hist, hist_load,
-                               h->precision, h->cus, h->wave_occ, nullptr, nullptr, 1, s};
+                               h->precision, h->cus, h->wave_occ, nullptr, nullptr, 1, 0, s};
         // QPs per work-counter atomic (scripts/claim_sweep.sh): one device-wide atomic per QP costs 10-50 % when QPs are short (two rows
         // per lane, the fp32 solve at three, closed-loop ticks); pairs coarsen the balance too much when they are long
+        WL.static_q = h->static_q;
         WL.claim_chunk = h->claim_chunk > 0 ? h->claim_chunk : ((rl <= 2 || (h->precision == 1 && rl == 3) || hist_load) ? 2 : 1);
         hipError_t werr = hipSuccess;
         int wrc = -1;

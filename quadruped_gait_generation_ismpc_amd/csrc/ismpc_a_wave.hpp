@@ -268,7 +268,7 @@ __global__ __launch_bounds__(WG, (wave_min_blocks<R, RL, PI>()))
 void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
                        const ismpc_a_inst* __restrict__ ipar, const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch,
                        int* __restrict__ work_counter, unsigned long long* __restrict__ hist, int hist_load,
-                       const int* __restrict__ order, const int* __restrict__ count_ptr, const int claim_chunk_)
+                       const int* __restrict__ order, const int* __restrict__ count_ptr, const int claim_chunk_, const int static_q)
 {
     using NM = Num<R>;
     const DevA& c = *cp;                                   // handle constants, read from memory where they are used (by value they would
@@ -302,16 +302,24 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     // device-wide atomic per QP is a floor of its own (every wavefront of the chip on one address)
     int claim_cur = 0, claim_end = 0;
     const int claim_chunk = max(claim_chunk_, 1);
+    // ... and the first static_q / 16 of the launch's QPs are dealt out without any atomic: wavefront g takes [g S, (g + 1) S)
+    const int total_qp = 2 * (count_ptr ? *count_ptr : batch);
+    const int nwaves = (int)gridDim.x * (WG / 64), gwave = (int)blockIdx.x * (WG / 64) + wv;
+    const int share = (int)(((long long)total_qp * static_q) / (16ll * nwaves));
+    int st_cur = gwave * share;
+    const int st_end = st_cur + share, dyn_base = nwaves * share;
     for (;;) {
-        if (claim_cur == claim_end) {
-            int claimed = 0;
-            if (lane == 0) claimed = atomicAdd(work_counter, claim_chunk);
-            claim_cur = __builtin_amdgcn_readfirstlane(claimed); claim_end = claim_cur + claim_chunk;
+        int work;
+        if (st_cur < st_end) work = st_cur++;
+        else {
+            if (claim_cur == claim_end) {
+                int claimed = 0;
+                if (lane == 0) claimed = atomicAdd(work_counter, claim_chunk);
+                claim_cur = __builtin_amdgcn_readfirstlane(claimed); claim_end = claim_cur + claim_chunk;
+            }
+            work = dyn_base + claim_cur++;
         }
-        const int work = claim_cur++;
-        // instances of this launch: all `batch` of them, or the `*count_ptr` listed in `order` (per-instance parameters: the
-        // host sorts the instances by their footstep count and runs each group through the kernel of that shape)
-        if (work >= 2 * (count_ptr ? *count_ptr : batch)) break;
+        if (work >= total_qp) break;
         const int inst = order ? order[work >> 1] : (work >> 1), axis = work & 1;
         const int qp = 2 * inst + axis;                    // slot of this QP in the working-set history
         const ismpc_a_state st = state_in[inst];
@@ -1327,7 +1335,7 @@ inline int launch_one(const WaveLaunch& L, hipError_t* err)
     }
     const int grid = std::min((2 * L.batch + 3) / 4, L.cus * occ);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), 0, L.stream, L.c_dev, L.prev, L.state, L.inst, L.push, L.out, L.batch, L.work_counter, L.hist, L.hist_load,
-                       L.order, L.count_ptr, L.claim_chunk);
+                       L.order, L.count_ptr, L.claim_chunk, L.static_q);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = e; return -2; }
     return 0;
