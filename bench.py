@@ -469,8 +469,13 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
         # data preparation, not the timed path: a nominal closed loop spreads the gait phases.  It runs on a second handle
         # with the OTHER arithmetic type, so that its 60 cheap launches carry another kernel name and a rocprofv3 --stats
         # summary of this process averages only the timed launches under the leg's kernel
+        # (an fp32 handle follows every launch with a one-workgroup fp64 launch for the QPs it could not solve: switched off on
+        # the preparation handle, or those would carry the fp64 leg's kernel name)
+        saved = os.environ.get("ISMPC_A_F32_RESOLVE"); os.environ["ISMPC_A_F32_RESOLVE"] = "0"
         prep = FA.GaitGenerator(FA.default_params(0, C=Cn, P=Pn, F=Fn), plans[0], device=R.local_rank,
                                 precision=("f32" if dtype == "f64" else "f64")); prep.add_plan(plans[1])
+        if saved is None: del os.environ["ISMPC_A_F32_RESOLVE"]
+        else: os.environ["ISMPC_A_F32_RESOLVE"] = saved
         prep.rollout_inst_torch(d0, d_inst, MC_PREROLL); torch.cuda.synchronize(); prep.close()
         tick = lambda st, pu: gen.tick_inst_torch(st, d_inst, pu)
         desc = (f"Formulation A Monte-Carlo (BASELINE configs[4] per-GPU shape): trot / walk by instance parity, C={Cn}, P={Pn}, per-instance CoM height "

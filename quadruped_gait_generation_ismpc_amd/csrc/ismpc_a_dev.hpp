@@ -37,6 +37,9 @@ struct WaveLaunch {
     const int* order; const int* count_ptr;       // NULL, or the instances of this launch (device list + device count): see tick_launch
     int claim_chunk;                              // QPs a wavefront takes from the work counter per atomic
     int static_q;                                 // sixteenths of the launch's QPs that are dealt out statically (no atomics) first
+    int order_is_qp;                              // order[] lists QPs (2 instance + axis) instead of instances: the fp64 re-solve of the few QPs
+    int* defer_list; int* defer_count;            // ... whose fp32 block solve failed its check (NULL: such a QP starts cold instead)
+    int grid_cap;                                 // > 0: at most this many workgroups (the re-solve launch)
     hipStream_t stream;
 };
 

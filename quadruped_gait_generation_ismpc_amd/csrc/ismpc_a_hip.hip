@@ -680,7 +680,8 @@ struct ismpc_a_handle {
                                                          // (measured slower: 6.2 vs 4.0 ms at 16 384 instances -- four tails of 100-iteration QPs instead of one)
     int precision = 0;                                   // 0: the QPs are solved in fp64, 1: in fp32 (ismpc_a_set_precision)
     DevA* c_dev = nullptr; bool c_dirty = true;          // the constants in device memory (what the wave kernels read), re-sent after a change
-    int* work_counter = nullptr;
+    int* work_counter = nullptr;                          // [0] the launch's counter, [1] the fp64 re-solve's, [2] deferred QPs of the fp32 launch
+    int* defer_list = nullptr; int defer_cap = 0; bool defer_off = false;   // fp32 solve: QPs handed to the fp64 instantiation (ISMPC_A_F32_RESOLVE=0: none)
     unsigned long long* hist = nullptr; int hist_cap = 0;   // per-QP working set of the previous tick (closed-loop first guess)
     int claim_chunk = 0;                                  // 0: by shape (tick_launch), else ISMPC_A_CLAIM
     int static_q = 8;                                     // sixteenths of a launch dealt out without atomics (ISMPC_A_STATIC; scripts/claim_sweep.sh:
@@ -821,6 +822,7 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     // ISMPC_A_WARM=add,drop,extra,min_viol,gi_first,peel,rounds,round_adds overrides; ISMPC_A_WARM=0 starts every QP cold
     c.warm_add = 6; c.warm_drop = 12; c.warm_extra = 0; c.warm_min_viol = 6; c.warm_gi = 2; c.warm_peel_end = 1;
     c.warm_rounds = 2; c.warm_round_adds = 8;
+    if (const char* e = std::getenv("ISMPC_A_F32_RESOLVE")) h->defer_off = std::atoi(e) == 0;
     if (const char* e = std::getenv("ISMPC_A_STATIC")) h->static_q = std::max(0, std::min(std::atoi(e), 16));
     if (const char* e = std::getenv("ISMPC_A_CLAIM")) h->claim_chunk = std::max(0, std::min(std::atoi(e), 64));   // 0: by shape
     if (const char* e = std::getenv("ISMPC_A_WARM")) {
@@ -882,7 +884,7 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
             h->slots = prop.multiProcessorCount * (c.sinv_in_lds ? 1 : 4);   // persistent grid: workgroups per CU
             const int scratch_slots = prop.multiProcessorCount * 4;          // the slab always covers the 4-per-CU grid (the LDS variant may fall back to it)
             h->wave_blocks = prop.multiProcessorCount * 4; h->cus = prop.multiProcessorCount;
-            if (hipMalloc((void**)&h->work_counter, sizeof(int)) != hipSuccess) rc = fail_a(-3, "counter allocation failed");
+            if (hipMalloc((void**)&h->work_counter, 4 * sizeof(int)) != hipSuccess) rc = fail_a(-3, "counter allocation failed");
             else h->allocs.push_back(h->work_counter);
             if (!rc) { if (hipMalloc((void**)&h->c_dev, sizeof(DevA)) != hipSuccess) rc = fail_a(-3, "constants allocation failed"); else h->allocs.push_back(h->c_dev); }
             if (const char* e = std::getenv("ISMPC_A_KERNEL")) h->use_wave = std::strcmp(e, "block") != 0;
@@ -909,6 +911,7 @@ void ismpc_a_destroy(ismpc_a_handle* h)
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->prev) (void)hipFree(h->prev);
     if (h->hist) (void)hipFree(h->hist);
+    if (h->defer_list) (void)hipFree(h->defer_list);
     if (h->order) (void)hipFree(h->order);
     if (h->feet_base) (void)hipFree(h->feet_base);
     delete h;
@@ -956,6 +959,12 @@ int ismpc_a_reserve(ismpc_a_handle* h, int max_batch)
         HIP_TRY_A(hipMalloc((void**)&h->order, sizeof(int) * (4 * (size_t)max_batch + 4)));
         h->order_cap = max_batch;
     }
+    if (max_batch > h->defer_cap) {
+        if (h->defer_list) HIP_TRY_A(hipFree(h->defer_list));
+        h->defer_list = nullptr; h->defer_cap = 0;
+        HIP_TRY_A(hipMalloc((void**)&h->defer_list, sizeof(int) * 2 * (size_t)max_batch));
+        h->defer_cap = max_batch;
+    }
     if (max_batch > h->hist_cap) {
         if (h->hist) HIP_TRY_A(hipFree(h->hist));
         h->hist = nullptr; h->hist_cap = 0; h->hist_valid = false;
@@ -999,10 +1008,10 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
     if (h->use_wave || inst_dev) {
         // structured solver, one wavefront per QP, 4 per workgroup; persistent grid (ismpc_a_wave.hpp)
         const int rl = (h->c.C + 63) / 64;
-        HIP_TRY_A(hipMemsetAsync(h->work_counter, 0, sizeof(int), s));
+        HIP_TRY_A(hipMemsetAsync(h->work_counter, 0, 4 * sizeof(int), s));
         if (h->c_dirty) { HIP_TRY_A(hipMemcpyAsync(h->c_dev, &h->c, sizeof(DevA), hipMemcpyHostToDevice, s)); h->c_dirty = false; }
         ismpc_a::WaveLaunch WL{h->c_dev, h->c.F, h->prev, state_dev, inst_dev, push_dev, out_dev, batch, h->work_counter, hist, hist_load,
-                               h->precision, h->cus, h->wave_occ, nullptr, nullptr, 1, 0, s};
+                               h->precision, h->cus, h->wave_occ, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, 0, s};
         // QPs per work-counter atomic (scripts/claim_sweep.sh): one device-wide atomic per QP costs 10-50 % when QPs are short (two rows
         // per lane, the fp32 solve at three, closed-loop ticks); pairs coarsen the balance too much when they are long
         WL.static_q = h->static_q;
@@ -1034,7 +1043,27 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
                 W.F = f; W.order = h->order + (size_t)(f - 3) * h->order_cap; W.count_ptr = counts + (f - 3);
                 wrc = go(W);
             }
-        } else wrc = go(WL);
+        } else {
+            const bool resolve = h->precision == 1 && !h->defer_off;
+            if (resolve) {
+                if (batch > h->defer_cap) {                  // stream-ordered growth, as the history
+                    if (h->defer_list) HIP_TRY_A(hipFreeAsync(h->defer_list, s));
+                    h->defer_list = nullptr; h->defer_cap = 0;
+                    HIP_TRY_A(hipMallocAsync((void**)&h->defer_list, sizeof(int) * 2 * (size_t)batch, s));
+                    h->defer_cap = batch;
+                }
+                WL.defer_list = h->defer_list; WL.defer_count = h->work_counter + 2;
+            }
+            wrc = go(WL);
+            if (wrc == 0 && resolve) {
+                // the QPs the fp32 launch handed over (block-solve check failed: a horizon pinned end to end), solved by the fp64
+                // instantiation: one workgroup, usually nothing to do
+                ismpc_a::WaveLaunch W2 = WL;
+                W2.precision = 0; W2.work_counter = h->work_counter + 1; W2.order = h->defer_list; W2.count_ptr = h->work_counter + 2;
+                W2.order_is_qp = 1; W2.defer_list = nullptr; W2.defer_count = nullptr; W2.static_q = 0; W2.claim_chunk = 1; W2.grid_cap = 1;
+                wrc = go(W2);
+            }
+        }
         if (wrc == 0) return 0;
         if (wrc == -2) return fail_a(-2, std::string("wave kernel launch: ") + hipGetErrorString(werr));
         if (inst_dev) return fail_a(-1, "per-instance gait parameters need the structured kernel: 3 <= F <= 6 and C <= 256");

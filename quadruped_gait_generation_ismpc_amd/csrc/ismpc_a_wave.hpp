@@ -268,7 +268,8 @@ __global__ __launch_bounds__(WG, (wave_min_blocks<R, RL, PI>()))
 void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
                        const ismpc_a_inst* __restrict__ ipar, const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch,
                        int* __restrict__ work_counter, unsigned long long* __restrict__ hist, int hist_load,
-                       const int* __restrict__ order, const int* __restrict__ count_ptr, const int claim_chunk_, const int static_q)
+                       const int* __restrict__ order, const int* __restrict__ count_ptr, const int claim_chunk_, const int static_q,
+                       const int order_is_qp, int* __restrict__ defer_list, int* __restrict__ defer_count)
 {
     using NM = Num<R>;
     const DevA& c = *cp;                                   // handle constants, read from memory where they are used (by value they would
@@ -303,7 +304,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     int claim_cur = 0, claim_end = 0;
     const int claim_chunk = max(claim_chunk_, 1);
     // ... and the first static_q / 16 of the launch's QPs are dealt out without any atomic: wavefront g takes [g S, (g + 1) S)
-    const int total_qp = 2 * (count_ptr ? *count_ptr : batch);
+    const int total_qp = order_is_qp ? *count_ptr : 2 * (count_ptr ? *count_ptr : batch);
     const int nwaves = (int)gridDim.x * (WG / 64), gwave = (int)blockIdx.x * (WG / 64) + wv;
     const int share = (int)(((long long)total_qp * static_q) / (16ll * nwaves));
     int st_cur = gwave * share;
@@ -320,7 +321,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             work = dyn_base + claim_cur++;
         }
         if (work >= total_qp) break;
-        const int inst = order ? order[work >> 1] : (work >> 1), axis = work & 1;
+        const int qpi = order_is_qp ? order[work] : work;
+        const int inst = (order && !order_is_qp) ? order[qpi >> 1] : (qpi >> 1), axis = qpi & 1;
         const int qp = 2 * inst + axis;                    // slot of this QP in the working-set history
         const ismpc_a_state st = state_in[inst];
         const double pos = axis == 0 ? st.x : st.y;
@@ -445,6 +447,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         }
         const R knrm = (lane >= 2) ? sq * R(0.70710678118654752440) : sq;   // 1 / |K_r|_{H^-1}: |kvec_r|^2 = 2 (r >= 2) or 1
         int iters = 0, qz = 0, qk = 0;
+        bool defer_qp = false;                                // fp32 solve: handed to the fp64 re-solve launch (see the block-solve check)
 #ifdef ISMPC_A_DIAG
         int dg_ns = 0, dg_cold = 0, dg_q0 = 0, dg_part = 0, dg_why = 0;   // diagnostic build (scripts/iters_hist.py): see the packing at the output
 #endif
@@ -879,6 +882,10 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #ifdef ISMPC_A_DIAG
                             dg_why = 1;
 #endif
+                            // fp32: a working set that pins (nearly) the whole horizon is beyond the block solve's accuracy, and the
+                            // cold start that follows is 100-150 one-row steps -- one such QP in 30 000 makes its launch 2-3x longer.
+                            // It goes to the fp64 instantiation instead (a one-workgroup launch right behind this one)
+                            if (sizeof(R) == 4 && defer_list != nullptr) defer_qp = true;
                             cold = true; break;
                         }
                     }
@@ -924,6 +931,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 dg_ns += nsolve; dg_cold = cold ? dg_why : 0; dg_q0 = cold ? 0 : qz;
 #endif
                 pass_solves = nsolve; pass_cold = cold;
+                if (defer_qp) break;
                 if (cold) {
 #pragma unroll
                     for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; SET_STA_(k, 0); mu[k] = R(0); pn[k] = 0; u[k] = (i <= C) ? t0 * ap[i - 1] : R(0); }
@@ -1221,7 +1229,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             // without any inactive row showing it.  One block solve of the final working set (kinematic rows included)
             // polishes such a point; if it still fails, the QP is reported infeasible (the reference's quadprog returns no
             // solution on infeasible QPs).
-            if (status == 0 && !done_opt) {
+            if (status == 0 && !done_opt && !defer_qp) {
                 auto off_point = [&]() __attribute__((always_inline)) -> bool {
                     R vv[RL], aul = R(0);
                     row_values(vv);
@@ -1263,6 +1271,11 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             }
         }
 
+        if (defer_qp) {                                       // nothing of this QP is written here: the fp64 re-solve owns it
+            if (lane == 0) defer_list[atomicAdd(defer_count, 1)] = qp;
+            WAVE_LDS_SYNC();
+            continue;
+        }
         if (hist != nullptr) {
             unsigned long long* hq = hist + (size_t)qp * 8;
 #pragma unroll
@@ -1333,9 +1346,10 @@ inline int launch_one(const WaveLaunch& L, hipError_t* err)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WG, 0) != hipSuccess || nb < 1) nb = 1;
         occ = nb;
     }
-    const int grid = std::min((2 * L.batch + 3) / 4, L.cus * occ);
+    int grid = std::min((2 * L.batch + 3) / 4, L.cus * occ);
+    if (L.grid_cap > 0) grid = std::min(grid, L.grid_cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), 0, L.stream, L.c_dev, L.prev, L.state, L.inst, L.push, L.out, L.batch, L.work_counter, L.hist, L.hist_load,
-                       L.order, L.count_ptr, L.claim_chunk, L.static_q);
+                       L.order, L.count_ptr, L.claim_chunk, L.static_q, L.order_is_qp, L.defer_list, L.defer_count);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = e; return -2; }
     return 0;
