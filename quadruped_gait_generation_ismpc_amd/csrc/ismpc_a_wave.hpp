@@ -533,6 +533,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #pragma unroll
                 for (int kk = 0; kk < m; ++kk) {                                 // Gauss-Jordan, no pivoting (quasi-definite)
                     if (kk > F && !((kmask >> (kk - F)) & 1ull)) continue;       // pinned unknown: its column is already e_kk
+                    if (PI && kk < F && kk >= Fi) continue;                      // footstep beyond this instance's horizon: no row maps to
+                                                                                 // it, its row and column of G are zero, the pivot is 1
                     const R ipv = frcp(rl(Tr[kk], kk));
                     const R fct = (lane == kk) ? R(0) : Tr[kk] * ipv;
 #pragma unroll
