@@ -537,7 +537,7 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
                          "algorithmic_bytes_per_launch": 136.0 * batch, "executed": executed,
                          "note": "algorithmic credit per SURVEY 8d: flops_A = 2[nv w^2 + w^3/3 + 4 nv w + 6 nv], nv = C+F, w = measured mean "
                                  "working-set size (a dense active-set solve); the structured solver executes less.  kernel_ms = HIP events "
-                                 "around the tick entry point (state copy + clear + the wave kernel; the wave kernel is > 99 % of it)"},
+                                 "around the tick entry point (state copy, clears, the wave kernel and, behind an fp32 launch, the one-workgroup fp64 re-solve launch; the wave kernel is 97-99 % of it: compare the rocprofv3 average under profiles/)"},
         }
     gen.close()
     return res
