@@ -618,10 +618,20 @@ __global__ void ismpc_a_bucket_by_F(const ismpc_a_inst* __restrict__ inst, int b
     order[(size_t)b * cap + atomicAdd(&counts[b], 1)] = i;
 }
 
-__global__ void ismpc_a_clear_out(ismpc_a_out* out, int batch)
+// Everything a tick needs before its solver launch, in one launch instead of a copy, a clear and a memset: the snapshot of the
+// state the two QPs of an instance read (the solver updates `state` in place), cleared flags of the output records, zeroed
+// work counters.  96-byte state records move as six 16-byte words per thread.
+__global__ void ismpc_a_tick_prologue(const ismpc_a_state* __restrict__ state, ismpc_a_state* __restrict__ prev, ismpc_a_out* out, int batch, int* counters)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < batch) { out[i].status = 0; out[i].active = 0; out[i].iters_x = 0; out[i].iters_y = 0; }
+    if (i < 4 && counters) counters[i] = 0;
+    if (i >= batch) return;
+    static_assert(sizeof(ismpc_a_state) % 16 == 0, "state record: whole 16-byte words");
+    const double2* src = reinterpret_cast<const double2*>(state + i);
+    double2* dst = reinterpret_cast<double2*>(prev + i);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(ismpc_a_state) / 16); ++k) dst[k] = src[k];
+    if (out) { out[i].status = 0; out[i].active = 0; out[i].iters_x = 0; out[i].iters_y = 0; }
 }
 
 struct DeviceGuardA {          // entry points leave the caller's current device as they found it
@@ -1003,12 +1013,11 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
         HIP_TRY_A(hipMallocAsync((void**)&h->prev, sizeof(ismpc_a_state) * (size_t)batch, s));
         h->prev_cap = batch;
     }
-    HIP_TRY_A(hipMemcpyAsync(h->prev, state_dev, sizeof(ismpc_a_state) * (size_t)batch, hipMemcpyDeviceToDevice, s));
-    if (out_dev) hipLaunchKernelGGL(ismpc_a_clear_out, dim3((batch + 255) / 256), dim3(256), 0, s, out_dev, batch);
+    hipLaunchKernelGGL(ismpc_a_tick_prologue, dim3((batch + 255) / 256), dim3(256), 0, s, (const ismpc_a_state*)state_dev, h->prev, out_dev, batch,
+                       (h->use_wave || inst_dev) ? h->work_counter : nullptr);
     if (h->use_wave || inst_dev) {
         // structured solver, one wavefront per QP, 4 per workgroup; persistent grid (ismpc_a_wave.hpp)
         const int rl = (h->c.C + 63) / 64;
-        HIP_TRY_A(hipMemsetAsync(h->work_counter, 0, 4 * sizeof(int), s));
         if (h->c_dirty) { HIP_TRY_A(hipMemcpyAsync(h->c_dev, &h->c, sizeof(DevA), hipMemcpyHostToDevice, s)); h->c_dirty = false; }
         ismpc_a::WaveLaunch WL{h->c_dev, h->c.F, h->prev, state_dev, inst_dev, push_dev, out_dev, batch, h->work_counter, hist, hist_load,
                                h->precision, h->cus, h->wave_occ, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, 0, s};
