@@ -212,6 +212,16 @@ template <typename V, int RL> __device__ __forceinline__ V at_row(const V (&v)[R
     for (int r = 1; r < RL; ++r) if (k == r) x = v[r];
     return rl(x, o);
 }
+// b^n, 0 <= n < 2048, by repeated squaring (per-instance gait parameters: every weight of the stability row and of the
+// anticipative tail is a power of lambda = exp(-eta dt); one exp per QP instead of seven, a pow, a cosh and a sinh)
+__device__ __forceinline__ double ipow(double b, int n)
+{
+    double r = 1.0;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { if (n & 1) r *= b; b *= b; n >>= 1; }
+    return r;
+}
+
 // element `e` (this lane's) of the border row V = [M~ (F), dt PA, Bk (F)] of a ZMP row with mapping (k1, w1, 1-w1), PA = pa
 template <typename R, int F> __device__ __forceinline__ R border_elem(int e, int k1, R w1, R pa, R dt, R isq)
 {
@@ -342,6 +352,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 status |= ISMPC_A_ST_BAD_INDEX; step_ = 2; ds_ = 1; Fi = 1; plan = 0; Qf_d = 1.0; eta = 1.0;
             } else eta = sqrt(c.grav / ip.height);
         }
+        const double lam_pi = PI ? exp(-eta * c.dt) : 0.0;   // per-instance eta: lambda = exp(-eta dt), the one transcendental of the QP
         const R Qf = (R)Qf_d, sq = (R)sqrt(Qf_d), isq = (R)(1.0 / sqrt(Qf_d)), iQf = (R)(1.0 / Qf_d);
         const float rstep = 1.0f / (float)step_;
         const double* fs = PI ? (axis == 0 ? c.plan_x[plan] : c.plan_y[plan]) : (axis == 0 ? c.fsx : c.fsy);
@@ -356,12 +367,13 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         if (PI) {
             // stability row a_i (quad_walk_no_plots.m:233-238), its prefix sums and a'a for this instance's eta
             R* aw = a_pi[PI ? wv : 0]; R* paw = pa_pi[PI ? wv : 0];
-            const double lam = exp(-eta * c.dt);
-            const double k1c = (1 / eta) * (1 - lam) / (1 - pow(lam, (double)C)), k2c = c.dt * 1.0 * exp(-eta * c.dt * C);
+            const double lam = lam_pi;
+            const double lamC = ipow(lam, C);
+            const double k1c = (1 / eta) * (1 - lam) / (1 - lamC), k2c = c.dt * 1.0 * lamC;
             double* padw = pad_pi[PI ? wv : 0]; double* pa2dw = pa2d_pi[PI ? wv : 0];
             double av[RL], cum[RL], cum2[RL], loc = 0.0, sqs = 0.0;
             // a_i = k1c lambda^i - k2c: one exp per lane (its first row), then powers of lambda
-            double lp = exp(-eta * c.dt * (lane * RL));
+            double lp = ipow(lam, lane * RL);
 #pragma unroll
             for (int k = 0; k < RL; ++k) {
                 const int i0 = lane * RL + k;
@@ -419,8 +431,9 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         double tl = 0.0;
         if (!(status & ISMPC_A_ST_BAD_INDEX)) {
             if (PI) {
-                const double om = 1 - exp(-eta * c.dt), l64 = exp(-eta * c.dt * 64);
-                double wi = exp(-eta * c.dt * (C + 1 + lane)) * om;
+                const double lam = lam_pi;
+                const double om = 1 - lam, l64 = ipow(lam, 64);
+                double wi = ipow(lam, C + 1 + lane) * om;
 #pragma nounroll
                 for (int i = C + 1 + lane; i <= P; i += 64) {
                     tl += wi * ((cl_closed(fs, step_, ds_, st.rebuilt != 0, j + i - 1) + cloff) - cur);
@@ -431,7 +444,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         }
         double tail = wave_sum(tl);
         if (!(status & ISMPC_A_ST_BAD_INDEX))
-            tail += PI ? exp(-eta * c.dt * P) * ((cl_closed(fs, step_, ds_, st.rebuilt != 0, P - 1) + cloff) - cur)
+            tail += PI ? ipow(lam_pi, P) * ((cl_closed(fs, step_, ds_, st.rebuilt != 0, P - 1) + cloff) - cur)
                        : c.wP * ((cl[P - 1] + cloff) - cur);
         const R beq = (R)(pos + vel / eta - zmp - tail);
         // ---- kinematic row r and footstep f_r (relative to the current one) live in lane r (1..F); Khat_r = sqrt(Qf) (f_r - f_{r-1})
@@ -1299,7 +1312,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             const double p0 = pos, v0 = vel, z0 = zmp;
             double np_, nv_, nz_;
             if (PI) {                                                            // A_upd, B_upd for this instance's eta (:67-71)
-                const double ch = cosh(eta * c.dt), sh = sinh(eta * c.dt);
+                const double e_ = lam_pi, ie_ = 1.0 / e_;
+                const double ch = 0.5 * (ie_ + e_), sh = 0.5 * (ie_ - e_);          // cosh, sinh of eta dt
                 np_ = (ch * p0 + (sh / eta) * v0 + (1 - ch) * z0) + (c.dt - sh / eta) * u0;
                 nv_ = ((eta * sh) * p0 + ch * v0 + (-eta * sh) * z0) + (1 - ch) * u0;
                 nz_ = (0.0 * p0 + 0.0 * v0 + 1.0 * z0) + c.dt * u0;
