@@ -236,14 +236,16 @@ template <typename R, int F> __device__ __forceinline__ R border_elem(int e, int
 
 // centreline value cl(k0+1) without the table: quad_walk_no_plots.m:86-99 (initial structure) / :540-549 (rebuilt one),
 // linspace as MATLAB evaluates it.  Used when step / ds differ per instance.
-__device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int step, int ds, bool rebuilt, int k0)
+__device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int step, float rstep, int ds, double inv_dsm1, bool rebuilt, int k0)
 {
-    const int s = k0 / step, r = k0 - s * step, q = r - (step - ds);
+    int s = (int)((float)k0 * rstep);                       // k0 / step without the integer-division sequence (rstep = 1 / step)
+    if (s * step > k0) --s; else if ((s + 1) * step <= k0) ++s;
+    const int r = k0 - s * step, q = r - (step - ds);
     const double d1 = fs[s];
     if (q <= 0 || (rebuilt && s == 0)) return d1;
     const double d2 = fs[s + 1];
     if (q == ds - 1) return d2;
-    return d1 + ((double)q * (d2 - d1)) / (double)(ds - 1);
+    return d1 + ((double)q * (d2 - d1)) * inv_dsm1;         // inv_dsm1 = 1 / (ds - 1)
 }
 
 // Residency target (wavefronts per SIMD = workgroups per CU, 256 threads each).  Measured with scripts/occ_sweep.sh on the
@@ -355,6 +357,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         const double lam_pi = PI ? exp(-eta * c.dt) : 0.0;   // per-instance eta: lambda = exp(-eta dt), the one transcendental of the QP
         const R Qf = (R)Qf_d, sq = (R)sqrt(Qf_d), isq = (R)(1.0 / sqrt(Qf_d)), iQf = (R)(1.0 / Qf_d);
         const float rstep = 1.0f / (float)step_;
+        const double inv_dsm1 = PI ? 1.0 / (double)(ds_ - 1) : 0.0, inv_ds = 1.0 / (double)ds_;
         const double* fs = PI ? (axis == 0 ? c.plan_x[plan] : c.plan_y[plan]) : (axis == 0 ? c.fsx : c.fsy);
         const double* cl = st.rebuilt ? (axis == 0 ? c.clx1 : c.cly1) : (axis == 0 ? c.clx0 : c.cly0);
         const double cloff = st.rebuilt ? off : 0.0;
@@ -415,7 +418,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 if (qd * step_ > j + i) --qd; else if ((qd + 1) * step_ <= j + i) ++qd;
                 int pf = qd - fc + 1; if (pf < 0) pf = 0;
                 const int rem = step_ * (fc + pf) - (j + i);
-                w1[k] = (rem > ds_) ? R(1) : (R)((double)rem / ds_);             // mapping(i, pf+1); the next column gets 1 - w1
+                w1[k] = (rem > ds_) ? R(1) : (R)((double)rem * inv_ds);          // mapping(i, pf+1) = rem / ds; the next column gets 1 - w1
                 ovf = ovf || pf > Fi || (rem <= ds_ && pf + 1 > Fi);
                 if (pf > 15) pf = 15;
                 ks[k] = pf | (1 << 4);
@@ -436,7 +439,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 double wi = ipow(lam, C + 1 + lane) * om;
 #pragma nounroll
                 for (int i = C + 1 + lane; i <= P; i += 64) {
-                    tl += wi * ((cl_closed(fs, step_, ds_, st.rebuilt != 0, j + i - 1) + cloff) - cur);
+                    tl += wi * ((cl_closed(fs, step_, rstep, ds_, inv_dsm1, st.rebuilt != 0, j + i - 1) + cloff) - cur);
                     wi *= l64;
                 }
             } else
@@ -444,7 +447,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         }
         double tail = wave_sum(tl);
         if (!(status & ISMPC_A_ST_BAD_INDEX))
-            tail += PI ? ipow(lam_pi, P) * ((cl_closed(fs, step_, ds_, st.rebuilt != 0, P - 1) + cloff) - cur)
+            tail += PI ? ipow(lam_pi, P) * ((cl_closed(fs, step_, rstep, ds_, inv_dsm1, st.rebuilt != 0, P - 1) + cloff) - cur)
                        : c.wP * ((cl[P - 1] + cloff) - cur);
         const R beq = (R)(pos + vel / eta - zmp - tail);
         // ---- kinematic row r and footstep f_r (relative to the current one) live in lane r (1..F); Khat_r = sqrt(Qf) (f_r - f_{r-1})
