@@ -22,6 +22,12 @@
 // symmetric, and all quantities the solver touches are step-sized: that is what lets the same code run in fp32 (Real = float:
 // right-hand sides are formed in fp64 and rounded once; the LIP update of the state stays fp64) as well as in fp64.
 //
+// Route of one solve (scripts/proto_passes.py): two exact Goldfarb-Idnani steps from the equality-only point, block
+// passes (every violated row enters at once; a negative run end leaves with the rows whose lumped multipliers stay <= 0; one
+// structured solve per pass), rounds of (exact steps, passes) while rows stay violated, Goldfarb-Idnani to the end, and a check
+// of the returned point.  Closed loops start the passes from the previous tick's working set.  An fp32 solve whose block solve
+// fails its check is handed to the fp64 instantiation (defer_list).
+//
 // Register budget: per row a lane keeps u, the mapping weight, the multiplier (Real), a float norm, and two packed ints
 // (first mapped footstep + state; previous / next active row).  The bounds are two wave-uniform numbers.
 #pragma once
