@@ -288,13 +288,17 @@ def flops_a(C, F, w):
     return 2.0 * (nv * w * w + w ** 3 / 3.0 + 4.0 * nv * w + 6.0 * nv)
 
 
-def _lpi():
-    return 8 if os.environ.get("ISMPC_LPI") == "8" else 16
+def _lpi(B):
+    """csrc/ismpc_hip.hip launch(): lanes per instance of the lane-group kernels (ISMPC_LPI, else 32 for batches <= 2 048, 16 above)."""
+    forced = {"8": 8, "16": 16, "32": 32}.get(os.environ.get("ISMPC_LPI"))
+    return forced if forced else (32 if B <= 2048 else 16)
 
 
 def _quad_r(N, lpi):
     """csrc/ismpc_hip.hip quad_R(): samples per lane of the lane-group kernels (smallest instantiated value that covers N)."""
     need = (N + lpi - 1) // lpi
+    if lpi == 32:
+        return 4
     if lpi == 16:
         return 4 if need <= 4 else (7 if need <= 7 else 8)
     return 8 if need <= 8 else (13 if need <= 13 else 16)
@@ -305,7 +309,7 @@ def one_launch(N, B, cus):
     path = os.environ.get("ISMPC_PATH")
     if path == "dense" or os.environ.get("ISMPC_Z_FALLBACK") == "0":
         return True
-    return (path != "wave" and N <= 128 and os.environ.get("ISMPC_ONE_LAUNCH") != "0" and (B * _lpi() + 63) // 64 <= 8 * cus)
+    return (path != "wave" and N <= 128 and os.environ.get("ISMPC_ONE_LAUNCH") != "0" and (B * _lpi(B) + 63) // 64 <= 8 * cus)
 
 
 def kernel_name_b(N, B, cus):
@@ -314,7 +318,7 @@ def kernel_name_b(N, B, cus):
         return "ismpc_tick_dense<%d, 16>" % ((N + 63) // 64)
     if path == "wave" or N > 128:
         return "ismpc_tick_affine<%d>" % ((N + 63) // 64)
-    lpi = _lpi()
+    lpi = _lpi(B)
     if one_launch(N, B, cus) and os.environ.get("ISMPC_Z_FALLBACK") != "0":
         return "ismpc_tick_quad_inline<%d, %d, %d>" % (_quad_r(N, lpi), lpi, (N + 63) // 64)
     return "ismpc_tick_quad<%d, %d>" % (_quad_r(N, lpi), lpi)

@@ -1122,6 +1122,39 @@ template <> struct Grp<16> {
     // v from the next lane of the group; the last lane gets `fill`
     __device__ static __forceinline__ double next_or(double fill, double v, int) { return dpp64<0x101, 0xf, false>(fill, v); }
 };
+// LPI = 32: two rows per group (two instances per wavefront; R = 4 samples per lane at N <= 128).  Row-local DPP steps as for
+// 16, one exchange with the partner row (lane ^ 16: ds_swizzle) for the sums, readlane of lanes 16 / 48 for the scan's fifth step.
+__device__ __forceinline__ double swz16(double v)       // the value of lane ^ 16
+{
+    return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F), __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F));
+}
+template <> struct Grp<32> {
+    static constexpr int STEPS = 5;
+    __device__ static __forceinline__ double sum(double v)
+    {
+        v += dpp64n<0x121, false>(v); v += dpp64n<0x122, false>(v); v += dpp64n<0x124, false>(v); v += dpp64n<0x128, false>(v);
+        return v + swz16(v);
+    }
+    __device__ static __forceinline__ int sum_i(int v)
+    {
+        v += __builtin_amdgcn_mov_dpp(v, 0x121, 0xf, 0xf, false); v += __builtin_amdgcn_mov_dpp(v, 0x122, 0xf, 0xf, false);
+        v += __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, false); v += __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false);
+        return v + __builtin_amdgcn_ds_swizzle(v, 0x401F);
+    }
+    // steps 0-3 stay inside a row (v from lane + 2^K of the ROW, 0 past its end); step 4 is grp_scan_step's own
+    template <int K> __device__ static __forceinline__ double shl0(double v, int) { return dpp64n<0x100 + (1 << K), true>(v); }
+    __device__ static __forceinline__ double bcast0(double v)
+    {
+        const double a = readlane64<0>(v), b = readlane64<32>(v);
+        return ((threadIdx.x & 32) != 0) ? b : a;
+    }
+    // v from the next lane of the group (wave_shl:1 crosses the row boundary); the last lane gets `fill`
+    __device__ static __forceinline__ double next_or(double fill, double v, int li)
+    {
+        const double t = dpp64<0x130, 0xf, false>(fill, v);
+        return (li == 31) ? fill : t;
+    }
+};
 template <> struct Grp<8> {
     static constexpr int STEPS = 3;
     __device__ static __forceinline__ double sum(double v)
@@ -1157,6 +1190,17 @@ template <> struct Grp<8> {
 template <int LPI, int K>
 __device__ __forceinline__ void grp_scan_step(M2& y, int li)
 {
+    if constexpr (LPI == 32 && K == 4) {
+        // the rows have their own suffix products; the lower row of a group still needs the upper row's total (its lane 16 / 48)
+        const bool g1 = (threadIdx.x & 32) != 0, low = li < 16;
+        const double ya = g1 ? readlane64<48>(y.a) : readlane64<16>(y.a), yb = g1 ? readlane64<48>(y.b) : readlane64<16>(y.b);
+        const double yc = g1 ? readlane64<48>(y.c) : readlane64<16>(y.c), yd = g1 ? readlane64<48>(y.d) : readlane64<16>(y.d);
+        const double ta = low ? ya - 1.0 : 0.0, tb = low ? yb : 0.0, tc = low ? yc : 0.0, td = low ? yd - 1.0 : 0.0;
+        M2 r;
+        r.a = fma(ta, y.a, fma(tb, y.c, y.a)); r.b = fma(ta, y.b, fma(tb, y.d, y.b));
+        r.c = fma(tc, y.a, fma(td, y.c, y.c)); r.d = fma(tc, y.b, fma(td, y.d, y.d));
+        y = r;
+    } else
     if constexpr (K < Grp<LPI>::STEPS) {
         const double ta = Grp<LPI>::template shl0<K>(y.a - 1.0, li), tb = Grp<LPI>::template shl0<K>(y.b, li);
         const double tc = Grp<LPI>::template shl0<K>(y.c, li), td = Grp<LPI>::template shl0<K>(y.d - 1.0, li);
@@ -1342,6 +1386,7 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
     for (int r = 1; r < R; ++r) Y = mul((M2){1.0 + ch1[r], s1[r], s2[r], 1.0 + ch1[r]}, Y);
     STAMP(2);                                         // tables arrived, lambda / A_j / local products done
     grp_scan_step<LPI, 0>(Y, li); grp_scan_step<LPI, 1>(Y, li); grp_scan_step<LPI, 2>(Y, li); grp_scan_step<LPI, 3>(Y, li);
+    grp_scan_step<LPI, 4>(Y, li);
     const double ie = c.inv_eta;
     const double cva = fma(ie, Y.c, Y.a), cvb = fma(ie, Y.d, Y.b);       // C_sc (suffix product from this lane's first sample)
     double c0 = Grp<LPI>::next_or(1.0, cva, li), c1 = Grp<LPI>::next_or(ie, cvb, li);                 // the lane needs it one lane up
@@ -1716,7 +1761,10 @@ struct ismpc_handle {
     bool dense_path = false;  // true: per-tick MFMA solve (ismpc_tick_dense); false: affine tables (ismpc_tick_affine)
     int cus = 0;              // compute units of the device (kernel variant selection); 0: never the one-launch variant
     bool quad_path = true;    // affine tables, several instances per wavefront (ismpc_tick_quad) where it applies; ISMPC_PATH=wave: one per wavefront
-    int lpi = 16;             // lanes per instance of the quad kernels: 16 (four instances per wavefront) or 8 (eight); ISMPC_LPI
+    int lpi = 16;             // lanes per instance of the quad kernels: 16 (four instances per wavefront), 8 (eight) or 32 (two); ISMPC_LPI
+    bool lpi_auto = true;     // no ISMPC_LPI: 32 lanes per instance for batches of <= LPI32_BATCH instances (scripts/lpi_batch.py: 1 us of 9-10
+                              // there, slower from 3 072 on), 16 otherwise; the tables exist in both layouts
+    const double* vqT32 = nullptr; const double* tzgT32 = nullptr;
     bool kernel_rollout = true;   // closed loops run inside one launch (ismpc_rollout_quad); ISMPC_ROLLOUT=host: one launch per tick
 };
 
@@ -1736,13 +1784,16 @@ int upload(ismpc_handle* h, const std::vector<T>& v, const T** dst)
 
 // Shape of the lane-group kernels for horizon N: samples per lane R (the smallest instantiated value that covers N) for
 // LPI = 16 / 8 lanes per instance; RW = samples per lane of the one-instance-per-wavefront fallback body.
+constexpr int LPI32_BATCH = 2048;
 int quad_R(int N, int lpi)
 {
     const int need = (N + lpi - 1) / lpi;
+    if (lpi == 32) return 4;
     if (lpi == 16) return need <= 4 ? 4 : (need <= 7 ? 7 : 8);
     return need <= 8 ? 8 : (need <= 13 ? 13 : 16);
 }
 #define ISMPC_SHAPES(X) \
+    if (lpi == 32) { if (h->c.N <= 64) X(4, 32, 1); else X(4, 32, 2); } else \
     if (lpi == 16) { if (RQ == 4) X(4, 16, 1); else if (RQ == 7) X(7, 16, 2); else X(8, 16, 2); } \
     else           { if (RQ == 8) X(8, 8, 1);   else if (RQ == 13) X(13, 8, 2); else X(16, 8, 2); }
 
@@ -1767,18 +1818,21 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
         const dim3 fgrid(std::min((batch + 3) / 4, 64));
         // default for N <= 128: several instances per wavefront (ismpc_tick_quad); ISMPC_PATH=wave keeps one per wavefront
         if (h->quad_path && h->c.N <= 128) {
-            const int lpi = h->lpi, RQ = quad_R(h->c.N, lpi);
+            const bool small = h->lpi_auto && h->vqT32 && batch <= LPI32_BATCH;
+            const int lpi = small ? 32 : h->lpi, RQ = quad_R(h->c.N, lpi);
+            DevConst cq = h->c;
+            if (small) { cq.vqT = h->vqT32; cq.tzgT = h->tzgT32; }
             const int waves = (batch * lpi + 63) / 64;
             const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
             // every wavefront resident at once (<= 2 per SIMD) and a fallback to run: one launch that handles deferred instances itself
             if (zm && h->cus > 0 && waves <= 8 * h->cus) {
-#define ISMPC_QUADI(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad_inline<RR, LL, RW_>), qgrid, qblock, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid)
+#define ISMPC_QUADI(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad_inline<RR, LL, RW_>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid)
                 ISMPC_SHAPES(ISMPC_QUADI)
 #undef ISMPC_QUADI
                 HIP_TRY(hipGetLastError());
                 return ISMPC_OK;
             }
-#define ISMPC_QUAD(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad<RR, LL>), qgrid, qblock, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid)
+#define ISMPC_QUAD(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad<RR, LL>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid)
             ISMPC_SHAPES(ISMPC_QUAD)
 #undef ISMPC_QUAD
             if (zm) {
@@ -1866,7 +1920,7 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     }
     if (const char* pth = std::getenv("ISMPC_PATH")) { h->dense_path = std::strcmp(pth, "dense") == 0; h->quad_path = std::strcmp(pth, "wave") != 0 && !h->dense_path; }
     if (const char* zf = std::getenv("ISMPC_Z_FALLBACK")) h->z_fallback = std::atoi(zf) != 0;   // 0: flag only, no second launch
-    if (const char* lp = std::getenv("ISMPC_LPI")) { const int v = std::atoi(lp); if (v == 8 || v == 16) h->lpi = v; }
+    if (const char* lp = std::getenv("ISMPC_LPI")) { const int v = std::atoi(lp); if (v == 8 || v == 16 || v == 32) { h->lpi = v; h->lpi_auto = false; } }
     if (const char* ro = std::getenv("ISMPC_ROLLOUT")) h->kernel_rollout = std::strcmp(ro, "host") != 0;
     DeviceGuard guard_(device);
     if (guard_.err != hipSuccess) { delete h; return fail(ISMPC_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard_.err)); }
@@ -1927,21 +1981,24 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
         if (rc == ISMPC_OK) rc = upload(h, tzg, &c.tzg);
         if (rc == ISMPC_OK) rc = upload(h, mxy, &c.midxy);
         if (rc == ISMPC_OK && t.p.N <= 128) {
-            // lane-contiguous copies for the lane-group kernels' shape (sample li*R + r of pattern p)
-            const int lpi = h->lpi, R = quad_R(t.p.N, lpi);
-            std::vector<double> vqT(npp * (size_t)R * 3 * lpi * 2), tzgT((size_t)R * lpi * 2);
-            for (size_t pp = 0; pp < npp; ++pp)
+            // lane-contiguous copies for the lane-group kernels' shapes (sample li*R + r of pattern p): the handle's layout and,
+            // when the layout is chosen per launch, the 32-lane one beside it
+            for (int pass = 0; pass < (h->lpi_auto ? 2 : 1) && rc == ISMPC_OK; ++pass) {
+                const int lpi = pass == 0 ? h->lpi : 32, R = quad_R(t.p.N, lpi);
+                std::vector<double> vqT(npp * (size_t)R * 3 * lpi * 2), tzgT((size_t)R * lpi * 2);
+                for (size_t pp = 0; pp < npp; ++pp)
+                    for (int r = 0; r < R; ++r)
+                        for (int k = 0; k < 3; ++k)
+                            for (int li = 0; li < lpi; ++li) {
+                                const int n = li * R + r;                       // < 128 <= NT
+                                const size_t dst = (((pp * R + r) * 3 + k) * lpi + li) * 2;
+                                vqT[dst] = vq[(pp * NTq + n) * 6 + 2 * k]; vqT[dst + 1] = vq[(pp * NTq + n) * 6 + 2 * k + 1];
+                            }
                 for (int r = 0; r < R; ++r)
-                    for (int k = 0; k < 3; ++k)
-                        for (int li = 0; li < lpi; ++li) {
-                            const int n = li * R + r;                       // < 128 <= NT
-                            const size_t dst = (((pp * R + r) * 3 + k) * lpi + li) * 2;
-                            vqT[dst] = vq[(pp * NTq + n) * 6 + 2 * k]; vqT[dst + 1] = vq[(pp * NTq + n) * 6 + 2 * k + 1];
-                        }
-            for (int r = 0; r < R; ++r)
-                for (int li = 0; li < lpi; ++li) { const int n = li * R + r; tzgT[((size_t)r * lpi + li) * 2] = t.tz[n]; tzgT[((size_t)r * lpi + li) * 2 + 1] = t.tg[n]; }
-            rc = upload(h, vqT, &c.vqT);
-            if (rc == ISMPC_OK) rc = upload(h, tzgT, &c.tzgT);
+                    for (int li = 0; li < lpi; ++li) { const int n = li * R + r; tzgT[((size_t)r * lpi + li) * 2] = t.tz[n]; tzgT[((size_t)r * lpi + li) * 2 + 1] = t.tg[n]; }
+                rc = upload(h, vqT, pass == 0 ? &c.vqT : &h->vqT32);
+                if (rc == ISMPC_OK) rc = upload(h, tzgT, pass == 0 ? &c.tzgT : &h->tzgT32);
+            }
         }
     }
     c.flat = t.flat ? 1 : 0;
@@ -2040,7 +2097,10 @@ int ismpc_rollout_device(ismpc_handle* h, int batch, ismpc_tick_in* state_dev, i
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
     if (batch > 0 && ticks > 0 && h->kernel_rollout && !h->dense_path && h->quad_path && h->c.N <= 128 && h->z_fallback) {
         // the whole closed loop in ONE launch: state in registers, one trajectory record per tick (ismpc_rollout_quad)
-        const int lpi = h->lpi, RQ = quad_R(h->c.N, lpi);
+        const bool small = h->lpi_auto && h->vqT32 && batch <= LPI32_BATCH;
+        const int lpi = small ? 32 : h->lpi, RQ = quad_R(h->c.N, lpi);
+        DevConst cq = h->c;
+        if (small) { cq.vqT = h->vqT32; cq.tzgT = h->tzgT32; }
         const int waves = (batch * lpi + 63) / 64;
         const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
         if (batch > h->zstop_cap) {                       // stream-ordered growth, as zmark (ismpc_reserve sizes it beforehand)
@@ -2052,8 +2112,8 @@ int ismpc_rollout_device(ismpc_handle* h, int batch, ismpc_tick_in* state_dev, i
         const int lid = ++h->launch_id;
         const dim3 rgrid(std::min((batch + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES, 64));
 #define ISMPC_ROLL(RR, LL, RW_) do { \
-        hipLaunchKernelGGL((ismpc_rollout_quad<RR, LL, RW_, false>), qgrid, qblock, 0, s, h->c, state_dev, traj_dev, batch, first_frame, ticks, h->zstop, lid); \
-        hipLaunchKernelGGL((ismpc_rollout_quad<RR, LL, RW_, true>), rgrid, qblock, 0, s, h->c, state_dev, traj_dev, batch, first_frame, ticks, h->zstop, lid); } while (0)
+        hipLaunchKernelGGL((ismpc_rollout_quad<RR, LL, RW_, false>), qgrid, qblock, 0, s, cq, state_dev, traj_dev, batch, first_frame, ticks, h->zstop, lid); \
+        hipLaunchKernelGGL((ismpc_rollout_quad<RR, LL, RW_, true>), rgrid, qblock, 0, s, cq, state_dev, traj_dev, batch, first_frame, ticks, h->zstop, lid); } while (0)
         ISMPC_SHAPES(ISMPC_ROLL)
 #undef ISMPC_ROLL
         HIP_TRY(hipGetLastError());

@@ -32,10 +32,12 @@ def O():
 
 
 _solvers = {}
-# affine tables with 16 lanes per instance (four instances per wavefront; default) / 8 lanes per instance (eight) / one instance
-# per wavefront; per-tick MFMA formulation
-PATHS = ("affine", "lpi8", "wave", "dense")
+# affine tables with 16 lanes per instance (four instances per wavefront; default) / 8 lanes per instance (eight) / 32 (two) / one
+# instance per wavefront; per-tick MFMA formulation
+PATHS = ("affine", "lpi8", "lpi32", "auto", "wave", "dense")
 _ENV = {"affine": {"ISMPC_PATH": "affine", "ISMPC_LPI": "16"}, "lpi8": {"ISMPC_PATH": "affine", "ISMPC_LPI": "8"},
+        "lpi32": {"ISMPC_PATH": "affine", "ISMPC_LPI": "32"}, "auto": {"ISMPC_PATH": "affine"},       # auto: 32 up to 2 048 instances, 16 above
+        "hostloop32": {"ISMPC_PATH": "affine", "ISMPC_LPI": "32", "ISMPC_ROLLOUT": "host"},
         "wave": {"ISMPC_PATH": "wave"}, "dense": {"ISMPC_PATH": "dense"},
         "hostloop": {"ISMPC_PATH": "affine", "ISMPC_LPI": "16", "ISMPC_ROLLOUT": "host"},
         "hostloop8": {"ISMPC_PATH": "affine", "ISMPC_LPI": "8", "ISMPC_ROLLOUT": "host"}}
@@ -149,7 +151,7 @@ def test_against_oracle_seeded(q, O, N, scale, path):
     assert_parity(q, out, ref, z_fallback=(path != "dense"))
 
 
-@pytest.mark.parametrize("lay", ["affine", "lpi8"])
+@pytest.mark.parametrize("lay", ["affine", "lpi8", "lpi32"])
 @pytest.mark.parametrize("N,over,dz", [(100, dict(z_ineq_hi=4.6), 0.0), (100, dict(z_ineq_hi=4.2), 0.0), (100, dict(z_ineq_hi=3.2), 0.0),
                                         (50, dict(), 0.12), (37, dict(), 0.10), (150, dict(z_ineq_hi=10.5), 0.0), (100, dict(), 0.25)])
 def test_vertical_inequality_rows_active(q, O, N, over, dz, lay):
@@ -351,7 +353,7 @@ def test_bitwise_reproducible_across_launch_variants_of_one_path(q, batch):
     assert torch.equal(o1, o2)
 
 
-@pytest.mark.parametrize("lay,host", [("affine", "hostloop"), ("lpi8", "hostloop8")])
+@pytest.mark.parametrize("lay,host", [("affine", "hostloop"), ("lpi8", "hostloop8"), ("lpi32", "hostloop32")])
 @pytest.mark.parametrize("N,ticks,over", [(100, 300, dict()), (50, 200, dict()), (100, 200, dict(z_ineq_hi=5.0)), (50, 200, dict(z_ineq_hi=1.3))])
 def test_in_kernel_rollout_is_bitwise_the_per_tick_loop(q, O, N, ticks, over, lay, host):
     """ismpc_rollout_device keeps the tick loop inside one launch (ismpc_rollout_quad); ISMPC_ROLLOUT=host runs one launch per
