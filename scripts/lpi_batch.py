@@ -13,6 +13,8 @@ solvers = {}
 for lpi in (16, 32):
     os.environ["ISMPC_LPI"] = str(lpi)
     solvers[lpi] = q.MPCSolver(q.reference_plan(params=p), params=p, device=0)
+os.environ["ISMPC_PATH"] = "wave"                          # one instance per wavefront (ismpc_tick_affine)
+solvers[64] = q.MPCSolver(q.reference_plan(params=p), params=p, device=0)
 for B in [int(a) for a in sys.argv[1:]] or [64, 256, 512, 1024, 2048, 3072, 4096, 6144, 8192, 16384]:
     d_in = q.to_device(workload.make_batch(N, B), "cuda:0"); d_out = torch.empty((B, 80), dtype=torch.uint8, device="cuda:0")
     res = {"batch": B}
