@@ -361,7 +361,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             } else eta = sqrt(c.grav / ip.height);
         }
         const double lam_pi = PI ? exp(-eta * c.dt) : 0.0;   // per-instance eta: lambda = exp(-eta dt), the one transcendental of the QP
-        const R Qf = (R)Qf_d, sq = (R)sqrt(Qf_d), isq = (R)(1.0 / sqrt(Qf_d)), iQf = (R)(1.0 / Qf_d);
+        const R sq = (R)sqrt(Qf_d), isq = (R)(1.0 / sqrt(Qf_d)), iQf = (R)(1.0 / Qf_d);
         const float rstep = 1.0f / (float)step_;
         const double inv_dsm1 = PI ? 1.0 / (double)(ds_ - 1) : 0.0, inv_ds = 1.0 / (double)ds_;
         const double* fs = PI ? (axis == 0 ? c.plan_x[plan] : c.plan_y[plan]) : (axis == 0 ? c.fsx : c.fsy);
