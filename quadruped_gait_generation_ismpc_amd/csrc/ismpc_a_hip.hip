@@ -830,7 +830,7 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     if (const char* e = std::getenv("ISMPC_A_BUCKET")) h->bucket_by_F = std::atoi(e) != 0;
     if (const char* e = std::getenv("ISMPC_A_PRECISION")) h->precision = (!std::strcmp(e, "f32") && p->F >= 3 && p->F <= 6) ? 1 : 0;   // A/B knob
     // ISMPC_A_WARM=add,drop,extra,min_viol,gi_first,peel,rounds,round_adds overrides; ISMPC_A_WARM=0 starts every QP cold
-    c.warm_add = 6; c.warm_drop = 12; c.warm_extra = 0; c.warm_min_viol = 6; c.warm_gi = 2; c.warm_peel_end = 1;
+    c.warm_add = 8; c.warm_drop = 12; c.warm_extra = 0; c.warm_min_viol = 6; c.warm_gi = 2; c.warm_peel_end = 1;
     c.warm_rounds = 2; c.warm_round_adds = 8;
     if (const char* e = std::getenv("ISMPC_A_F32_RESOLVE")) h->defer_off = std::atoi(e) == 0;
     if (const char* e = std::getenv("ISMPC_A_STATIC")) h->static_q = std::max(0, std::min(std::atoi(e), 16));
