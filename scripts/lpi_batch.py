@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lanes per instance of the Formulation B lane-group kernels against the batch size: us per step of ismpc_solve_batch_device
-(HIP events over 200 steps) for ISMPC_LPI = 16 and 32.  usage: python scripts/lpi_batch.py [batch ...]"""
+(HIP events over 200 steps) for ISMPC_LPI = 8, 16 and 32 and for the one-instance-per-wavefront kernel.  usage: python scripts/lpi_batch.py [batch ...]"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +10,7 @@ from quadruped_gait_generation_ismpc_amd import workload
 N = 100
 p = q.default_params(N=N)
 solvers = {}
-for lpi in (16, 32):
+for lpi in (8, 16, 32):
     os.environ["ISMPC_LPI"] = str(lpi)
     solvers[lpi] = q.MPCSolver(q.reference_plan(params=p), params=p, device=0)
 os.environ["ISMPC_PATH"] = "wave"                          # one instance per wavefront (ismpc_tick_affine)
