@@ -300,7 +300,12 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     __shared__ R rinv[WG + 1];                              // 1 / g for the index gaps g = 1 .. C between active rows (a read instead of a division)
     __shared__ double pad_s[PI ? 1 : WG + 1], pa2d_s[PI ? 1 : WG + 1];
     __shared__ double pad_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1], pa2d_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1];
-    const int lane = threadIdx.x & 63;
+    // `lane` is re-declared opaque (LANE_FRESH) at the head of every solver phase: comparisons against it (lane == k, lane < m, the
+    // fold masks ...) are loop invariants, the compiler hoists dozens of 64-bit masks out of the persistent loop, they do not fit
+    // the scalar register file and every use then restores its mask from a spill VGPR lane by lane (two v_readlane and a wait
+    // state against one v_cmp to recompute it)
+    int lane = threadIdx.x & 63;
+#define LANE_FRESH() asm volatile("" : "+v"(lane))
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds<R, F>& L = lds_all[wv];
     const int C = c.C, P = c.P;
@@ -328,6 +333,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     int st_cur = gwave * share;
     const int st_end = st_cur + share, dyn_base = nwaves * share;
     for (;;) {
+        LANE_FRESH();
         int work;
         if (st_cur < st_end) work = st_cur++;
         else {
@@ -487,6 +493,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 
             // row values at the current point: v_i = dt cumsum(u)_i - M_i f, in vv[]; leaves f in L.fl
             auto row_values = [&](R (&vv)[RL]) __attribute__((always_inline)) {
+                LANE_FRESH();
                 if (lane <= F + 1) L.fl[lane] = fr;
                 WAVE_LDS_SYNC();
                 R lc = R(0);
@@ -533,6 +540,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             // 0..F-1 footstep columns, F = stability row, F+1..2F = Khat_1..F (rows outside kmask: pinned to 0).  Returns
             // this lane's cc[lane] and leaves cc in L.cc.
             auto solve_small = [&](const unsigned long long kmask) __attribute__((always_inline)) -> R {
+                LANE_FRESH();
                 // lane i < m owns row i of the augmented matrix in registers; the pivot row travels by readlane: no LDS
                 // traffic and no barriers inside the elimination
                 const int i = lane < m ? lane : m - 1;
@@ -574,6 +582,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             // ---- one structured solve for a whole working set (the ZMP rows in ks[], the kinematic rows in kmask / kact):
             // minimiser u, f and all multipliers; leaves G(W) in L.G and prv / nxt of every row
             auto block_solve = [&](const unsigned long long kmask) __attribute__((always_inline)) {
+                LANE_FRESH();
                 // ---- previous / next active row of every row (active or not): exclusive max scan, exclusive suffix min scan
                 int nact = 0;
                 R cvr[RL];
@@ -794,6 +803,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     }
                 }
                 for (int pass = 0; ; ++pass) {
+                    LANE_FRESH();
                     const bool adding = pass < c.warm_add || force_add;
                     force_add = false;
                     // ---- row values at the current point; the new working set
@@ -976,6 +986,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             bool gi_leave = false;                                // feasible, or failed: nothing more to do
             for (;;) {
                 // ================= most violated inactive row =================
+                LANE_FRESH();
                 R cand = R(0), craw = R(0); int code = 0;
                 {
                     R vv[RL];
@@ -1028,6 +1039,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 bool failed = false, fresh = true;                                // fresh: sviol still valid from the search
                 // ================= steps until the row enters (Goldfarb-Idnani) =================
                 for (;;) {
+                    LANE_FRESH();
                     if (++iters > c.max_iter) { status |= ISMPC_A_ST_ITER_LIMIT; failed = true; break; }
                     // ---- violation of the row at the current point (after a partial step)
                     if (!fresh) {
@@ -1255,6 +1267,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             // solution on infeasible QPs).
             if (status == 0 && !done_opt && !defer_qp) {
                 auto off_point = [&]() __attribute__((always_inline)) -> bool {
+                    LANE_FRESH();
                     R vv[RL], aul = R(0);
                     row_values(vv);
                     bool bad = false;
@@ -1308,6 +1321,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 if (lane == 0) { hq[k] = lo_; hq[4 + k] = hi_; }
             }
         }
+        LANE_FRESH();
         // ---- LIP update (:297-322), footstep bookkeeping (:522-556), outputs: fp64 whatever the precision of the solve
 #ifdef ISMPC_A_DIAG
         // bits 0-9 work (as in the product build) | 10-13 block solves | 14-15 why the solve started cold (1 check, 2 budget) |
