@@ -255,9 +255,9 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 }
 
 // Residency target (wavefronts per SIMD = workgroups per CU, 256 threads each).  Measured with scripts/occ_sweep.sh on the
-// round-2 solver (MI355X, 16 384 pushed instances): fp32 3 for two and three rows per lane (3.3e7 vs 3.2e7 ticks/s at 4 for
-// walk C=100; 2.59e7 vs 2.45e7 at 2 for walk C=150), 2 for four rows per lane (Monte-Carlo C=200: 1.18e7 vs 9.3e6 at 3, the
-// 168-register budget spills 160 registers there); fp64 2 everywhere (walk C=100: 3.2e7 vs 2.9e7 at 3; 1 halves the rate).
+// round-2 solver (MI355X, 16 384 pushed instances) after the lane masks stopped living in spilled scalar registers: fp32 3
+// everywhere (4 changes nothing for two rows per lane; four rows per lane -- the Monte-Carlo shape -- 2.54e7 ticks/s at 3
+// against 1.95e7 at 2: 14 spilled registers now, 160 before); fp64 2 everywhere (1 halves the rate, 3 does not fit).
 #ifndef ISMPC_A_OCC_F32_RL2      // tuning knobs (scripts/occ_sweep.sh builds variants)
 #define ISMPC_A_OCC_F32_RL2 3
 #endif
@@ -265,7 +265,7 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 #define ISMPC_A_OCC_F32_RL3 3
 #endif
 #ifndef ISMPC_A_OCC_F32_RL4
-#define ISMPC_A_OCC_F32_RL4 2
+#define ISMPC_A_OCC_F32_RL4 3
 #endif
 #ifndef ISMPC_A_OCC_F64_RL2
 #define ISMPC_A_OCC_F64_RL2 2
