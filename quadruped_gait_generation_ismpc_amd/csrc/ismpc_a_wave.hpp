@@ -257,7 +257,8 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 // Residency target (wavefronts per SIMD = workgroups per CU, 256 threads each).  Measured with scripts/occ_sweep.sh on the
 // round-2 solver (MI355X, 16 384 pushed instances) after the lane masks stopped living in spilled scalar registers: fp32 3
 // everywhere (4 changes nothing for two rows per lane; four rows per lane -- the Monte-Carlo shape -- 2.54e7 ticks/s at 3
-// against 1.95e7 at 2: 14 spilled registers now, 160 before); fp64 2 everywhere (1 halves the rate, 3 does not fit).
+// against 1.95e7 at 2: 14 spilled registers now, 160 before); fp64 3 for two rows per lane (walk C=100: 5.2e7 against 4.3e7 at 2,
+// 8 spilled registers), 2 beyond (1 halves the rate, 3 does not fit).
 #ifndef ISMPC_A_OCC_F32_RL2      // tuning knobs (scripts/occ_sweep.sh builds variants)
 #define ISMPC_A_OCC_F32_RL2 3
 #endif
@@ -268,13 +269,15 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 #define ISMPC_A_OCC_F32_RL4 3
 #endif
 #ifndef ISMPC_A_OCC_F64_RL2
-#define ISMPC_A_OCC_F64_RL2 2
+#define ISMPC_A_OCC_F64_RL2 3
 #endif
 #ifndef ISMPC_A_OCC_F64_RL34
 #define ISMPC_A_OCC_F64_RL34 2
 #endif
-template <typename R, int RL, bool PI> constexpr int wave_min_blocks()
+template <typename R, int RL, int F, bool PI> constexpr int wave_min_blocks()
 {
+    if (sizeof(R) == 8 && RL <= 2 && (PI || F > 4)) return 2;   // per-instance: 56-62 KB of LDS per workgroup, two fit a CU whatever the
+                                                                // registers allow; five and six footsteps: 29 / 61 spilled registers at 3
     return sizeof(R) == 4 ? (RL <= 2 ? ISMPC_A_OCC_F32_RL2 : (RL == 3 ? ISMPC_A_OCC_F32_RL3 : ISMPC_A_OCC_F32_RL4))
                           : (RL <= 2 ? ISMPC_A_OCC_F64_RL2 : ISMPC_A_OCC_F64_RL34);
 }
@@ -282,7 +285,7 @@ template <typename R, int RL, bool PI> constexpr int wave_min_blocks()
 // RL = ZMP rows per lane (C <= 64 RL), F = footsteps in the horizon (m = 2F+1 border columns).
 // PI: per-instance gait parameters (ismpc_a_inst): height, Qf, step, ds, F <= the template F, base plan.
 template <typename R, int RL, int F, bool PI>
-__global__ __launch_bounds__(WG, (wave_min_blocks<R, RL, PI>()))
+__global__ __launch_bounds__(WG, (wave_min_blocks<R, RL, F, PI>()))
 void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restrict__ state_in, ismpc_a_state* __restrict__ state,
                        const ismpc_a_inst* __restrict__ ipar, const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch,
                        int* __restrict__ work_counter, unsigned long long* __restrict__ hist, int hist_load,
