@@ -258,7 +258,8 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 // round-2 solver (MI355X, 16 384 pushed instances) after the lane masks stopped living in spilled scalar registers: fp32 3
 // everywhere (4 changes nothing for two rows per lane; four rows per lane -- the Monte-Carlo shape -- 2.54e7 ticks/s at 3
 // against 1.95e7 at 2: 14 spilled registers now, 160 before); fp64 3 for two rows per lane (walk C=100: 5.2e7 against 4.3e7 at 2,
-// 8 spilled registers), 2 beyond (1 halves the rate, 3 does not fit).
+// 8 spilled registers) and for three (walk C=150: 3.44e7 against 3.0e7 at 2, trot C=160 3.0e7 against 2.55e7, with 50 spilled
+// registers); 2 for four rows per lane and for per-instance parameters (LDS).
 #ifndef ISMPC_A_OCC_F32_RL2      // tuning knobs (scripts/occ_sweep.sh builds variants)
 #define ISMPC_A_OCC_F32_RL2 3
 #endif
@@ -271,15 +272,18 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 #ifndef ISMPC_A_OCC_F64_RL2
 #define ISMPC_A_OCC_F64_RL2 3
 #endif
-#ifndef ISMPC_A_OCC_F64_RL34
-#define ISMPC_A_OCC_F64_RL34 2
+#ifndef ISMPC_A_OCC_F64_RL3
+#define ISMPC_A_OCC_F64_RL3 3
+#endif
+#ifndef ISMPC_A_OCC_F64_RL4
+#define ISMPC_A_OCC_F64_RL4 2
 #endif
 template <typename R, int RL, int F, bool PI> constexpr int wave_min_blocks()
 {
     if (sizeof(R) == 8 && RL <= 2 && (PI || F > 4)) return 2;   // per-instance: 56-62 KB of LDS per workgroup, two fit a CU whatever the
                                                                 // registers allow; five and six footsteps: 29 / 61 spilled registers at 3
     return sizeof(R) == 4 ? (RL <= 2 ? ISMPC_A_OCC_F32_RL2 : (RL == 3 ? ISMPC_A_OCC_F32_RL3 : ISMPC_A_OCC_F32_RL4))
-                          : (RL <= 2 ? ISMPC_A_OCC_F64_RL2 : ISMPC_A_OCC_F64_RL34);
+                          : (RL <= 2 ? ISMPC_A_OCC_F64_RL2 : ((RL == 3 && !PI) ? ISMPC_A_OCC_F64_RL3 : ISMPC_A_OCC_F64_RL4));
 }
 
 // RL = ZMP rows per lane (C <= 64 RL), F = footsteps in the horizon (m = 2F+1 border columns).

@@ -4,10 +4,10 @@
 set -e
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 mkdir -p build/variants gpurun_out
-VARIANTS=("a:3:3:2:2:2" "b:4:3:2:2:2" "c:4:3:3:2:2")   # f32 RL2 : f32 RL3 : f32 RL4 : f64 RL2 : f64 RL3,4
+VARIANTS=("a:3:3:3:3:3" "b:3:3:3:2:2" "c:4:3:3:3:2")   # f32 RL2 : f32 RL3 : f32 RL4 : f64 RL2 : f64 RL3 (RL4: 2)
 if [ "$1" = build ]; then
   for v in "${VARIANTS[@]}"; do IFS=: read n a b b4 c d <<< "$v"
-    python -c "from quadruped_gait_generation_ismpc_amd import build; build.build(out='build/variants/libismpc_occ_$n.so', flags='-DISMPC_A_OCC_F32_RL2=$a -DISMPC_A_OCC_F32_RL3=$b -DISMPC_A_OCC_F32_RL4=$b4 -DISMPC_A_OCC_F64_RL2=$c -DISMPC_A_OCC_F64_RL34=$d')" &
+    python -c "from quadruped_gait_generation_ismpc_amd import build; build.build(out='build/variants/libismpc_occ_$n.so', flags='-DISMPC_A_OCC_F32_RL2=$a -DISMPC_A_OCC_F32_RL3=$b -DISMPC_A_OCC_F32_RL4=$b4 -DISMPC_A_OCC_F64_RL2=$c -DISMPC_A_OCC_F64_RL3=$d -DISMPC_A_OCC_F64_RL4=2')" &
   done; wait; ls -la build/variants; exit 0
 fi
 : > gpurun_out/occ_sweep.log
