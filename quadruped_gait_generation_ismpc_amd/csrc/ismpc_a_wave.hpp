@@ -255,8 +255,9 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 }
 
 // Residency target (wavefronts per SIMD = workgroups per CU, 256 threads each).  Measured with scripts/occ_sweep.sh on the
-// round-2 solver (MI355X, 16 384 pushed instances) after the lane masks stopped living in spilled scalar registers: fp32 3
-// everywhere (4 changes nothing for two rows per lane; four rows per lane -- the Monte-Carlo shape -- 2.54e7 ticks/s at 3
+// round-2 solver (MI355X, 16 384 pushed instances) after the lane masks stopped living in spilled scalar registers: fp32 4 for
+// three rows per lane (128 registers, 5 spilled: walk C=150 4.7e7 against 4.1e7 ticks/s at 3, trot C=160 4.2e7 against 3.7e7), 3
+// and for four (Monte-Carlo: 2.65e7 against 2.54e7 at 3, 1.95e7 at 2; 55 spilled), 3 for two rows per lane (4 changes nothing; four rows per lane -- the Monte-Carlo shape -- 2.54e7 ticks/s at 3
 // against 1.95e7 at 2: 14 spilled registers now, 160 before); fp64 3 for two rows per lane (walk C=100: 5.2e7 against 4.3e7 at 2,
 // 8 spilled registers) and for three (walk C=150: 3.44e7 against 3.0e7 at 2, trot C=160 3.0e7 against 2.55e7, with 50 spilled
 // registers); 2 for four rows per lane and for per-instance parameters (LDS).
@@ -264,10 +265,10 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 #define ISMPC_A_OCC_F32_RL2 3
 #endif
 #ifndef ISMPC_A_OCC_F32_RL3
-#define ISMPC_A_OCC_F32_RL3 3
+#define ISMPC_A_OCC_F32_RL3 4
 #endif
 #ifndef ISMPC_A_OCC_F32_RL4
-#define ISMPC_A_OCC_F32_RL4 3
+#define ISMPC_A_OCC_F32_RL4 4
 #endif
 #ifndef ISMPC_A_OCC_F64_RL2
 #define ISMPC_A_OCC_F64_RL2 3
