@@ -38,11 +38,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_FP64_TFLOPS = 78.6      # MI355X FP64 vector = matrix peak (AMD spec)
-PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md
+# VALU peaks the executed flops are priced against: 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz = 78.6 TFLOP/s for
+# v_fma_f64 AND for the unpacked v_fma_f32 the fp32 solve issues (the library is built -fno-slp-vectorize: no v_pk_fma_f32,
+# which is what the 157.3 TFLOP/s FP32 spec figure assumes).  profiles/r03/valu_peak.json holds the rates measured on the box.
+PEAK_TFLOPS = {"f64": 78.6, "f32": 78.6}
+PEAK_NOTE = ("78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz: the FP64 vector (= matrix) peak, and the peak of UNPACKED fp32 FMAs "
+             "(the fp32 kernels issue no v_pk_*; the 157.3 TFLOP/s spec figure needs packed fp32).  Measured rates: profiles/r03/valu_peak.json")
 CLOCK_GHZ = 2.4              # MI355X_MICROARCH.md "Max clock"
 SIMDS = 256 * 4
-PROFILES = os.path.join(ROOT, "profiles", "r02")
+PROFILES = os.path.join(ROOT, "profiles", "r03")
 GLOBAL_BATCH = 65536
 HORIZON = 100
 A_BATCH = 16384
@@ -159,15 +163,68 @@ def cpu_baseline(leg, unit, budget_s, sample_desc, unit_per_n=1, horizon=HORIZON
 # ======================================================================================================================
 # GPU side
 # ======================================================================================================================
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def spawn_ranks(n, argv, timeout_s=3000):
+    """`python bench.py --gpus N` as typed (no torch.distributed.run around it): THIS process touches no GPU -- it starts one
+    rank process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment, the same
+    variables torch.distributed.run sets), forwards rank 0's JSON line and exits non-zero if any rank does.  A rank that
+    dies takes the others with it (they would wait in a collective for ever): exact PIDs only."""
+    import tempfile
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ISMPC_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = tempfile.TemporaryFile(mode="w+") if r == 0 else subprocess.DEVNULL
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT, stdout=out))
+    t0, rc = time.time(), 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is not None:
+                live.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    print(f"bench.py: rank {r} exited with {c}; stopping the other ranks", file=sys.stderr, flush=True)
+        if (rc != 0 or time.time() - t0 > timeout_s) and live:
+            if rc == 0:
+                rc = 124; print("bench.py: ranks timed out", file=sys.stderr, flush=True)
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill(); procs[r].wait()
+            live.clear()
+        if live:
+            time.sleep(0.2)
+    outs[0].seek(0)
+    text = outs[0].read()
+    sys.stdout.write(text); sys.stdout.flush()
+    if rc == 0 and not any(l.startswith("{") for l in text.splitlines()):
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr); rc = 1
+    return rc
+
+
 class Ranks:
-    def __init__(self, gpus):
+    def __init__(self, gpus, force_collective=False):
         import torch
         self.torch = torch
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != gpus and self.world == 1 and gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        if self.world != gpus:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world}: start `python bench.py --gpus N` (it spawns its own ranks) or "
+                             "torch.distributed.run --nproc-per-node N bench.py --gpus N")
         assert torch.cuda.is_available(), "bench.py needs an MI355X: the hot path has no CPU fallback"
         # ISMPC_BENCH_REHEARSE=1: rehearsal of the multi-rank control flow on a ONE-GPU box -- every rank uses cuda:0 and the
         # all-gather runs over gloo on host copies.  Not a measurement (the JSON line says so); the driver never sets it.
@@ -177,9 +234,15 @@ class Ranks:
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         self.dist = None
-        if self.world > 1:
+        # force_collective: a ONE-rank RCCL group, so that the path's collective (communicator set-up, the side-stream
+        # all-gather and its event order) runs on a one-GPU box too -- over a group of one rank it moves no bytes between GPUs
+        self.collective = self.world > 1 or force_collective
+        if self.collective:
             import torch.distributed as dist
             self.dist = dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                os.environ["MASTER_PORT"] = str(_free_port())
             if self.rehearse:
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             else:
@@ -197,7 +260,7 @@ class Ranks:
         return float(t.item())
 
     def close(self):
-        if self.world > 1:
+        if self.dist is not None:
             self.dist.destroy_process_group()
 
 
@@ -246,9 +309,9 @@ class RegionEvents:
 
 
 def load_pmc(leg):
-    """profiles/r02/pmc_<leg>.json (scripts/profile_r02.sh + scripts/pmc_summary.py): counters of the dominant kernel,
+    """profiles/r03/pmc_<leg>.json (scripts/profile_r03.sh + scripts/pmc_summary.py): counters of the dominant kernel,
     mean per launch, collected on exactly this leg's batch -- never scaled from another batch."""
-    path = os.path.join(PROFILES, f"pmc_{leg}.json")
+    path = os.path.join(os.environ.get("ISMPC_PROFILES_DIR") or PROFILES, f"pmc_{leg}.json")
     if not os.path.exists(path):
         return None
     try:
@@ -257,24 +320,57 @@ def load_pmc(leg):
         return None
 
 
-def executed_work(leg, kernel, kernel_ms, batch):
-    """What the kernel executes, from the committed PMC pass of this leg: VALU instructions per launch x 4 cycles (one
-    wave64 FP64 instruction occupies the 16-lane pipe for 4 cycles) / 1 024 SIMDs / 2.4 GHz = the time the vector pipes
-    are issuing, over the measured kernel time; HBM bytes per launch (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE)."""
+def roofline(leg, kernel, kernel_ms, batch, dtype, alg_flops, alg_bytes, extra=None, note=""):
+    """The contract's roofline object for one leg.  `achieved` / `frac` are a MEASUREMENT of what the kernel executes: the
+    floating-point wave-instructions the SQ counted for this kernel on this batch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_{F64,F32},
+    committed under profiles/r03/) x 64 lanes, FMA = 2 flop, over the kernel's own launch duration (HIP events, live), against
+    the VALU peak of the arithmetic type.  The SURVEY 8d figure (a dense solve the kernels do not run) is kept beside it as
+    `algorithmic_credit` and carries no fraction.  `issue` is the time the vector pipes spend issuing ALL VALU instructions
+    (4 cycles per wave64 instruction per SIMD) over the same duration -- also <= 1 by construction."""
     j = load_pmc(leg)
+    peak = PEAK_TFLOPS[dtype]
+    rf = {"bound": "valu", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
+          "kernel": kernel, "kernel_ms": kernel_ms,
+          "algorithmic_credit": {"flops_per_launch": alg_flops, "tflops": alg_flops / (kernel_ms * 1e-3) / 1e12, "bytes_per_launch": alg_bytes,
+                                 "note": "SURVEY 8d per-tick figure x instances per launch / kernel_ms; not a fraction of anything the kernel executes"},
+          "executed": None, "peak_note": PEAK_NOTE, "note": note}
+    if extra:
+        rf.update(extra)
     if not j or j.get("batch") != batch or j.get("kernel", "") not in kernel:
-        return None, None
-    c = j.get("counters_mean_per_launch", {})
-    ex = None
+        rf["note"] += "  (no PMC summary for this leg / batch under profiles/r03: achieved, frac, traffic left null)"
+        return rf
+    c, d = j.get("counters_mean_per_launch", {}), j.get("derived", {})
+    per_step = float(j.get("launches_per_step", 1))
+    fl64, fl32 = d.get("flops_f64_per_launch"), d.get("flops_f32_per_launch")
+    ex = {"source": f"profiles/r03/pmc_{leg}.json"}
+    if fl64 is not None and fl32 is not None:
+        flops = (fl64 + fl32) * per_step
+        rf["achieved"] = flops / (kernel_ms * 1e-3) / 1e12
+        rf["frac"] = rf["achieved"] / peak
+        ex.update({"flops_f64_per_launch": fl64 * per_step, "flops_f32_per_launch": fl32 * per_step,
+                   "fp_wave_instructions_per_launch": (d.get("fp_insts_f64_per_launch", 0.0) + d.get("fp_insts_f32_per_launch", 0.0)) * per_step,
+                   "fp_share_of_valu_instructions": d.get("fp_share_of_valu_insts")})
     if "SQ_INSTS_VALU" in c:
-        per_step = float(j.get("launches_per_step", 1))                 # a step of the per-instance legs is several launches
         valu = c["SQ_INSTS_VALU"] * per_step
         issue_ms = valu * 4.0 / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
-        ex = {"valu_insts_per_launch": valu, "valu_issue_ms": issue_ms, "valu_issue_frac": issue_ms / kernel_ms,
-              "mfma_insts_per_launch": c.get("SQ_INSTS_VALU_MFMA_F64", 0.0) if "SQ_INSTS_VALU_MFMA_F64" in c else None,
-              "source": f"profiles/r02/pmc_{leg}.json"}
-    hbm = j.get("derived", {}).get("hbm_bytes_per_launch")
-    return ex, (hbm * float(j.get("launches_per_step", 1)) if hbm is not None else None)
+        ex.update({"valu_insts_per_launch": valu, "valu_issue_ms": issue_ms, "valu_issue_frac": issue_ms / kernel_ms,
+                   "mfma_f64_mops_per_launch": c.get("SQ_INSTS_VALU_MFMA_MOPS_F64")})
+    rf["executed"] = ex
+    hbm = d.get("hbm_bytes_per_launch")
+    rf["traffic"] = hbm * per_step if hbm is not None else None
+    return rf
+
+
+def isolated_ms(torch, fn, reps=40):
+    """One launch alone: synchronize, event, launch, event, synchronize; median over reps.  This is what rocprofv3 reports per
+    dispatch.  In a train of back-to-back launches (what `value` measures) the tail of launch k and the head of launch k+1
+    overlap, so the per-launch interval of a train is SHORTER than an isolated launch -- the two numbers are reported apart."""
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return statistics.median(ts)
 
 
 def flops_b(N):
@@ -339,7 +435,7 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
     d_out = [torch.empty((B, 80), dtype=torch.uint8, device=R.dev) for _ in range(2)]
     cus = torch.cuda.get_device_properties(R.dev).multi_processor_count
     pipe = None
-    if world > 1:
+    if R.collective:
         pipe = GatherPipeline(world, B, 80, device=("cpu" if R.rehearse else R.dev), host_copies=R.rehearse)
 
     def step(k):
@@ -355,20 +451,20 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
     wall = statistics.median(walls)
     step_interval_ms = ev.median_ms(K)
 
-    # ---- dominant kernel alone (roofline): same inputs, K back-to-back launches bracketed by one event pair per region
-    kernel_ms = step_interval_ms
-    if world > 1 or not one_launch(N, B, cus):
-        solo = solver
-        if not one_launch(N, B, cus):
-            os.environ["ISMPC_Z_FALLBACK"] = "0"                         # the normally idle second launch switched off
-            try:
-                solo = q.MPCSolver(q.reference_plan(params=p), params=p, device=R.local_rank)
-            finally:
-                del os.environ["ISMPC_Z_FALLBACK"]
-        d_tmp = torch.empty_like(d_out[0])
-        ev2 = RegionEvents(torch)
-        timed_regions(R, lambda k: solo.solve_batch_torch(d_in, d_tmp), K, W, min_ms, ev=(ev2.start, ev2.end))
-        kernel_ms = ev2.median_ms(K)
+    # ---- dominant kernel alone (roofline): same inputs.  Two durations: a train of K back-to-back launches (per-launch
+    # interval, event pair per region) and ONE launch between synchronisations (what rocprofv3 reports per dispatch)
+    solo = solver
+    if not one_launch(N, B, cus):
+        os.environ["ISMPC_Z_FALLBACK"] = "0"                             # the normally idle second launch switched off
+        try:
+            solo = q.MPCSolver(q.reference_plan(params=p), params=p, device=R.local_rank)
+        finally:
+            del os.environ["ISMPC_Z_FALLBACK"]
+    d_tmp = torch.empty_like(d_out[0])
+    ev2 = RegionEvents(torch)
+    timed_regions(R, lambda k: solo.solve_batch_torch(d_in, d_tmp), K, W, min_ms, ev=(ev2.start, ev2.end))
+    kernel_ms_train = ev2.median_ms(K)
+    kernel_ms = isolated_ms(torch, lambda: solo.solve_batch_torch(d_in, d_tmp))
     collective_ms = None
     if pipe is not None:
         ev3 = RegionEvents(torch)
@@ -389,9 +485,7 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
     if rank == 0:
         value = global_batch / (wall / K)
         flops = flops_b(N) * B
-        achieved = flops / (kernel_ms * 1e-3) / 1e12
         kname = kernel_name_b(N, B, cus)
-        executed, traffic = executed_work(leg, kname, kernel_ms, B)
         res = {
             "value": value, "unit": "ticks/s (1 tick = one MPCSolver::solve = 3 QPs: vertical + x + y)",
             "ms_per_step": 1e3 * wall / K, "dtype": "f64", "qp_solves_per_s": 3.0 * value,
@@ -399,26 +493,21 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
             "config": {"workload": f"Formulation B (MPCSolver::solve), trot plan Controller.cpp:89-97, N={N}, S=35, F=10, fp64, "
                                    f"global batch {global_batch} ({B} instances/GPU), nominal pre-roll + perturbation (SURVEY 8d)",
                        "horizon": N, "global_batch": global_batch, "batch_per_gpu": B,
-                       "collective": ("one RCCL all-gather of 80-byte output records per step, side stream, double-buffered "
-                                      "(overlaps the next step's kernel)") if world > 1 else "none (1 GPU)",
+                       "collective": (f"one RCCL all-gather of 80-byte output records per step over {world} rank(s), side stream, double-buffered "
+                                      "(overlaps the next step's kernel)") if pipe is not None else "none (1 GPU)",
                        "flight_fraction": float(((st & q.ST_FLIGHT) != 0).mean()),
                        "infeasible_fraction": float(((st & (q.ST_X_INFEASIBLE | q.ST_Y_INFEASIBLE)) != 0).mean()),
                        "z_inequality_active_fraction": float(((st & q.ST_Z_INEQ_ACTIVE) != 0).mean()),
                        "active_box_fraction": active_box},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic,
-                         "kernel": kname, "kernel_ms": kernel_ms, "step_interval_ms": step_interval_ms,
-                         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": 152.0 * B,
-                         "executed": executed,
-                         "note": "bound: FP64 VECTOR issue (the kernel issues no MFMA; MI355X FP64 vector peak = matrix peak = 78.6 TF, which "
-                                 "is the number the contract's 'mfma' slot would hold).  achieved / frac = ALGORITHMIC credit per SURVEY 8d "
-                                 "(6N^2+20N flop per tick: the reference's dense vertical solve with a batch-shared factor) / kernel_ms -- the "
-                                 "kernel evaluates that solve from affine tables, so frac is not pipe utilisation and grows with batch; "
-                                 "executed.valu_issue_frac is: measured VALU instructions x 4 cycles / 1024 SIMDs / 2.4 GHz / kernel_ms.  "
-                                 "traffic = HBM bytes per launch from the PMC pass of this batch (algorithmic: 152 B/tick, ~1e-4 of the HBM roofline)"},
+            "roofline": roofline(leg, kname, kernel_ms, B, "f64", flops, 152.0 * B,
+                                 extra={"kernel_ms_train": kernel_ms_train, "step_interval_ms": step_interval_ms},
+                                 note="kernel_ms = ONE launch between synchronisations (HIP events; agrees with the rocprofv3 per-dispatch average under "
+                                      "profiles/r03); kernel_ms_train = per-launch interval of back-to-back launches of the same kernel (consecutive "
+                                      "launches overlap head to tail, so it is shorter and is what `value` is made of); step_interval_ms = the same for the "
+                                      "whole step (kernel + the normally idle fallback launch).  No MFMA on this path: bound = FP64 vector issue."),
         }
-        if collective_ms is not None or world > 1:
-            res["multi_gpu"] = {"kernel_ms": kernel_ms, "collective_ms": collective_ms, "overlapped_step_ms": 1e3 * wall / K}
+        if pipe is not None:
+            res["multi_gpu"] = {"kernel_ms": kernel_ms_train, "collective_ms": collective_ms, "overlapped_step_ms": 1e3 * wall / K}
         if extras and world == 1:
             # PCIe-inclusive rate through the host-pointer entry point (pageable numpy buffers in and out) -- never `value`
             solver.solve_batch(tick_in[:64])
@@ -498,7 +587,7 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
         per_inst = False
     dpush = torch.from_numpy(push.copy()).to(R.dev)
     d = d0.clone()
-    all_out = torch.empty((world * batch, 80), dtype=torch.uint8, device=("cpu" if R.rehearse else R.dev)) if world > 1 else None
+    all_out = torch.empty((world * batch, 80), dtype=torch.uint8, device=("cpu" if R.rehearse else R.dev)) if R.collective else None
     last = [None]
     evs = []
 
@@ -507,8 +596,8 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); o = tick(d, dpush); b.record(); evs.append((a, b))
         last[0] = o
-        if world > 1:
-            gather_records(o.cpu() if R.rehearse else o, world, out=all_out, counts=[batch] * world)
+        if all_out is not None:
+            gather_records(o.cpu() if R.rehearse else o, world, out=all_out, counts=[batch] * world, force=True)
 
     walls = timed_regions(R, step, K, W, min_ms)
     wall = statistics.median(walls)
@@ -520,11 +609,8 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
         act = ((o["active"] & 0xffff) + (o["active"] >> 16)) / 2.0
         wmean = float(act.mean())
         flops = flops_a(Cn, Fn, wmean) * batch
-        peak = PEAK_FP64_TFLOPS if dtype == "f64" else PEAK_FP32_TFLOPS
-        achieved = flops / (kernel_ms * 1e-3) / 1e12
         kname = a_kernel_name(Cn, Fn, per_inst, dtype)
         legkey = leg if dtype == "f64" else f"{leg}_{dtype}"
-        executed, traffic = executed_work(legkey, kname, kernel_ms, batch)
         value = world * batch / (wall / K)
         res = {
             "value": value, "unit": "ticks/s (1 tick = 2 per-axis QPs of C+F variables)", "ms_per_step": 1e3 * wall / K, "dtype": dtype,
@@ -536,13 +622,15 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
                        "iterations_per_qp_max": int(max(o["iters_x"].max(), o["iters_y"].max())),
                        "working_set_mean": wmean, "working_set_max": int(max((o["active"] & 0xffff).max(), (o["active"] >> 16).max())),
                        "active_box_fraction": float(((o["active"] & 0xffff) > 1).mean() / 2 + ((o["active"] >> 16) > 1).mean() / 2)},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "kernel": kname, "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
-                         "algorithmic_bytes_per_launch": 136.0 * batch, "executed": executed,
-                         "note": "algorithmic credit per SURVEY 8d: flops_A = 2[nv w^2 + w^3/3 + 4 nv w + 6 nv], nv = C+F, w = measured mean "
-                                 "working-set size (a dense active-set solve); the structured solver executes less.  kernel_ms = HIP events "
-                                 "around the tick entry point (state copy, clears, the wave kernel and, behind an fp32 launch, the one-workgroup fp64 re-solve launch; the wave kernel is 97-99 % of it: compare the rocprofv3 average under profiles/)"},
+            "roofline": roofline(legkey, kname, kernel_ms, batch, dtype, flops, 136.0 * batch,
+                                 note="kernel_ms = HIP events around every tick call of the timed regions, median (the state copy precedes the first event; "
+                                      "prologue launch, the wave kernel and, behind an fp32 launch, the fp64 re-solve launch inside; the wave kernel is 97-99 % "
+                                      "of it: compare the rocprofv3 average under profiles/r03).  algorithmic_credit = SURVEY 8d flops_A = 2[nv w^2 + w^3/3 + "
+                                      "4 nv w + 6 nv], nv = C+F, w = measured mean working-set size (a dense active-set solve; the structured solver executes "
+                                      "less).  fp32 legs execute fp64 instructions too (right-hand sides, prefix sums, the LIP update): both types are counted."),
         }
+        if dtype == "f32":
+            res["config"]["deferred_to_fp64"] = int(gen.last_deferred())
     gen.close()
     return res
 
@@ -567,9 +655,27 @@ def main():
     ap.add_argument("--only", default=None, help="run ONE leg and print it as the line: headline | config1_b1024 | config3_walk_C150 | "
                                                   "config4_mc_C200 | shard_b8192 | a_walk_C100 | a_trot_C160 (profiling runs: one kernel shape per process)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="with --only <Formulation A leg>: arithmetic type of the QP solve")
+    ap.add_argument("--spawn", action="store_true", help="start the rank processes from this process even for --gpus 1 (the launcher path of `--gpus N` as typed)")
+    ap.add_argument("--force-collective", action="store_true", help="build the RCCL group and run the path's all-gather even with ONE rank "
+                                                                     "(exercises communicator set-up and the side-stream pipeline on a one-GPU box; moves no bytes between GPUs)")
+    ap.add_argument("--launcher-selftest", type=int, default=None, help=argparse.SUPPRESS)   # rank that fails (-1: none); no GPU is touched
     args = ap.parse_args()
+    if os.environ.get("ISMPC_BENCH_CHILD") != "1" and (args.spawn or (args.gpus > 1 and "WORLD_SIZE" not in os.environ)):
+        # the launcher never touches the GPU (a process that did must not be replaced or forked around): it only starts the ranks
+        sys.exit(spawn_ranks(args.gpus, [a for a in sys.argv[1:] if a != "--spawn"]))
 
-    R = Ranks(args.gpus)
+    if args.launcher_selftest is not None:
+        # what a rank process sees, without touching a GPU (tests/test_distributed.py::test_bench_launcher_*)
+        r = int(os.environ.get("RANK", "0"))
+        if r == 0:
+            print(json.dumps({"rank": r, "world": int(os.environ.get("WORLD_SIZE", "1")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                              "master": os.environ.get("MASTER_ADDR"), "port": int(os.environ.get("MASTER_PORT", "0")), "gpus": args.gpus}), flush=True)
+        if r == args.launcher_selftest:
+            sys.exit(7)
+        time.sleep(0.5 if args.launcher_selftest < 0 else 30)
+        return
+
+    R = Ranks(args.gpus, force_collective=args.force_collective)
     world, rank = R.world, R.rank
     import quadruped_gait_generation_ismpc_amd as q
     K, W, M = args.steps, args.warmup, args.min_region_ms

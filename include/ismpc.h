@@ -27,6 +27,7 @@
 #ifndef ISMPC_H
 #define ISMPC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -119,9 +120,25 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows,
 void ismpc_destroy(ismpc_handle* h);
 
 /* One MPCSolver::solve per instance, `batch` independent instances.
- * Host pointers; copies in, runs, copies out, returns when done.           */
+ * Host pointers; copies in, runs, copies out, returns when done
+ * (Controller.cpp:346-348: by value in, by value out).
+ * Batches of >= 8 192 records in PAGE-LOCKED buffers (hipHostMalloc,
+ * hipHostRegister, or the ismpc_host_* helpers below) run as a pipeline of
+ * chunks on two streams: copy-in of chunk k+1, the kernel of chunk k and
+ * copy-out of chunk k-1 overlap; results are bit-identical to the
+ * device-pointer entry point.  Pageable buffers work too, serially (the HIP
+ * runtime stages them), and batches of <= 64 records are read and written by
+ * the kernel in place (host memory mapped into the device).                */
 int ismpc_solve_batch(ismpc_handle* h, int batch,
                       const ismpc_tick_in* in_host, ismpc_tick_out* out_host);
+
+/* Page-locked host memory without HIP headers on the caller's side: allocate
+ * record buffers with ismpc_host_alloc, or pin existing ones for as long as
+ * they live with ismpc_host_register (unregister BEFORE freeing them).       */
+int ismpc_host_alloc(size_t bytes, void** out);
+int ismpc_host_free(void* p);
+int ismpc_host_register(void* p, size_t bytes);
+int ismpc_host_unregister(void* p);
 
 /* Same, device pointers, enqueued on `stream` (a hipStream_t; NULL = the
  * default stream), asynchronous.  `u_traj` is NULL or a device buffer of
@@ -129,7 +146,9 @@ int ismpc_solve_batch(ismpc_handle* h, int batch,
  * (decisionVariables_z/_x/_y, MPCSolver.cpp:269,395,396).
  * A handle owns scratch that its launches share (the per-instance marks of the
  * inequality fallback): launches of ONE handle must be ordered -- one stream, or
- * streams synchronised by the caller.  Independent handles are independent.  */
+ * streams synchronised by the caller.  Independent handles are independent.
+ * When that scratch has to grow inside a call whose stream is not the previous
+ * call's, the previous stream is drained first (ismpc_reserve avoids both).   */
 int ismpc_solve_batch_device(ismpc_handle* h, int batch,
                              const ismpc_tick_in* in_dev, ismpc_tick_out* out_dev,
                              double* u_traj, void* stream);

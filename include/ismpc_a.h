@@ -17,8 +17,11 @@
  *
  * The swing-foot re-placement QPs, the foot trajectories and the text wire format are the
  * ismpc_a_*feet* / ismpc_a_foot_trajectories / ismpc_a_write_trajectory_txt entry points further down.
- * Conventions as ismpc.h: plain C, int status, no CPU fallback; launches of one handle must be ordered (the handle owns
- * the copy of the previous state, the work counter and the working-set history that its launches share).
+ * Conventions as ismpc.h: plain C, int status, no CPU fallback; every entry point runs on the handle's device and restores
+ * the caller's current one.  Launches of one handle must be ordered (the handle owns the copy of the previous state, the
+ * work counter and the working-set history that its launches share): use one stream per handle, or order the streams
+ * yourself.  When that scratch has to grow inside an asynchronous entry point and the call's stream is not the previous
+ * call's, the previous stream is drained first (ismpc_a_reserve avoids both the growth and the wait).
  */
 #ifndef ISMPC_A_H
 #define ISMPC_A_H
@@ -131,6 +134,9 @@ int ismpc_a_rollout_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_de
  * fp32 block solve; it is solved by the fp64 instantiation in a one-workgroup launch that follows every fp32 launch on the
  * same stream (about one QP in 30 000 at pushes 1.5x the bench's).  Needs 3 <= F <= 6. */
 int ismpc_a_set_precision(ismpc_a_handle* h, int fp32);
+
+/* Introspection (synchronises the stream of the last launch): QPs the last fp32 launch handed to the fp64 re-solve. */
+int ismpc_a_last_deferred(ismpc_a_handle* h);
 
 /* The same first guess for caller-driven loops of ismpc_a_tick_batch*_device: enable it when instance i of one call is
  * instance i of the previous one (a wrong guess costs time, never accuracy).  Off by default. */

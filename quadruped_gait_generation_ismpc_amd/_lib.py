@@ -31,7 +31,8 @@ assert TICK_IN.itemsize == 72 and TICK_OUT.itemsize == 80
 EXPORTS = ["ismpc_params_default", "ismpc_create", "ismpc_destroy", "ismpc_solve_batch",
            "ismpc_solve_batch_device", "ismpc_rollout_device", "ismpc_abi_version", "ismpc_last_error",
            "ismpc_get_params", "ismpc_midpoint_rows", "ismpc_get_midpoint", "ismpc_set_timing",
-           "ismpc_last_kernel_ms", "ismpc_reserve"]
+           "ismpc_last_kernel_ms", "ismpc_reserve", "ismpc_host_alloc", "ismpc_host_free", "ismpc_host_register",
+           "ismpc_host_unregister"]
 
 _lib = None
 
@@ -72,9 +73,34 @@ def load():
     lib.ismpc_set_timing.argtypes = [vp, ci]; lib.ismpc_set_timing.restype = ci
     lib.ismpc_last_kernel_ms.argtypes = [vp]; lib.ismpc_last_kernel_ms.restype = cd
     lib.ismpc_reserve.argtypes = [vp, ci]; lib.ismpc_reserve.restype = ci
+    lib.ismpc_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]; lib.ismpc_host_alloc.restype = ci
+    lib.ismpc_host_free.argtypes = [vp]; lib.ismpc_host_free.restype = ci
+    lib.ismpc_host_register.argtypes = [vp, C.c_size_t]; lib.ismpc_host_register.restype = ci
+    lib.ismpc_host_unregister.argtypes = [vp]; lib.ismpc_host_unregister.restype = ci
     _lib = lib
     return lib
 
 
 def last_error():
     return load().ismpc_last_error().decode()
+
+
+class PinnedRecords:
+    """A numpy array of records in page-locked host memory (ismpc_host_alloc): what the pipelined host entry point
+    ismpc_solve_batch wants on both sides.  `.array` is the view; the memory is freed when this object is."""
+
+    def __init__(self, n, dtype):
+        import weakref
+        lib = load()
+        self._p = C.c_void_p()
+        nbytes = max(int(n), 1) * np.dtype(dtype).itemsize
+        rc = lib.ismpc_host_alloc(nbytes, C.byref(self._p))
+        if rc != 0:
+            raise MemoryError(f"ismpc_host_alloc({nbytes}): {rc}: {last_error()}")
+        buf = (C.c_uint8 * nbytes).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(n))
+        self._fin = weakref.finalize(self, lib.ismpc_host_free, C.c_void_p(self._p.value))
+
+    def free(self):
+        self.array = None
+        self._fin()

@@ -691,6 +691,7 @@ struct ismpc_a_handle {
     int precision = 0;                                   // 0: the QPs are solved in fp64, 1: in fp32 (ismpc_a_set_precision)
     DevA* c_dev = nullptr; bool c_dirty = true;          // the constants in device memory (what the wave kernels read), re-sent after a change
     int* work_counter = nullptr;                          // [0] the launch's counter, [1] the fp64 re-solve's, [2] deferred QPs of the fp32 launch
+    int resolve_grid = 64;                                // workgroups of the fp64 re-solve launch behind an fp32 launch (ISMPC_A_RESOLVE_GRID)
     int* defer_list = nullptr; int defer_cap = 0; bool defer_off = false;   // fp32 solve: QPs handed to the fp64 instantiation (ISMPC_A_F32_RESOLVE=0: none)
     unsigned long long* hist = nullptr; int hist_cap = 0;   // per-QP working set of the previous tick (closed-loop first guess)
     int claim_chunk = 0;                                  // 0: by shape (tick_launch), else ISMPC_A_CLAIM
@@ -698,6 +699,8 @@ struct ismpc_a_handle {
                                                           // half is +2-12 % on every bench leg, three quarters starts to cost balance)
     bool hist_ticks = false, hist_valid = false;           // use it in plain tick calls too / it holds the previous tick of this batch
     int hist_batch = 0; bool hist_off = false;            // ISMPC_A_HISTORY=0: never (A/B)
+    hipStream_t last_stream = nullptr; bool used = false; // stream of the previous launch: scratch that outlives a call is re-allocated only
+                                                          // after that stream has drained (grow_sync)
     std::vector<void*> allocs;
     std::vector<double> fsx, fsy;
 };
@@ -833,6 +836,7 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     c.warm_add = 8; c.warm_drop = 12; c.warm_extra = 0; c.warm_min_viol = 6; c.warm_gi = 2; c.warm_peel_end = 1;
     c.warm_rounds = 2; c.warm_round_adds = 8;
     if (const char* e = std::getenv("ISMPC_A_F32_RESOLVE")) h->defer_off = std::atoi(e) == 0;
+    if (const char* e = std::getenv("ISMPC_A_RESOLVE_GRID")) h->resolve_grid = std::max(1, std::min(std::atoi(e), 1024));
     if (const char* e = std::getenv("ISMPC_A_STATIC")) h->static_q = std::max(0, std::min(std::atoi(e), 16));
     if (const char* e = std::getenv("ISMPC_A_CLAIM")) h->claim_chunk = std::max(0, std::min(std::atoi(e), 64));   // 0: by shape
     if (const char* e = std::getenv("ISMPC_A_WARM")) {
@@ -984,6 +988,15 @@ int ismpc_a_reserve(ismpc_a_handle* h, int max_batch)
     return 0;
 }
 
+// The handle's scratch (prev, hist, order, defer_list) outlives the call that allocated it and is used by later calls on
+// whatever stream those pass.  Before it is re-allocated on stream `s`, the previous launch's stream -- if it is another
+// one -- is drained: the free can then not overtake kernels that still use the block.
+static hipError_t grow_sync(ismpc_a_handle* h, hipStream_t s)
+{
+    if (h->used && h->last_stream != s) return hipStreamSynchronize(h->last_stream);
+    return hipSuccess;
+}
+
 static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev, const double* push_dev,
                        ismpc_a_out* out_dev, void* stream, int history = -1)
 {
@@ -997,7 +1010,7 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
     unsigned long long* hist = nullptr;
     if (history > 0) {
         if (batch > h->hist_cap) {                       // stream-ordered growth; ismpc_a_reserve sizes it beforehand
-            if (h->hist) HIP_TRY_A(hipFreeAsync(h->hist, s));
+            HIP_TRY_A(grow_sync(h, s)); if (h->hist) HIP_TRY_A(hipFreeAsync(h->hist, s));
             h->hist = nullptr; h->hist_cap = 0; h->hist_valid = false;
             HIP_TRY_A(hipMallocAsync((void**)&h->hist, sizeof(unsigned long long) * 16 * (size_t)batch, s));
             h->hist_cap = batch;
@@ -1007,8 +1020,9 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
         h->hist_valid = true; h->hist_batch = batch;
     }
     const int hist_load = history == 2 ? 1 : 0;
+    struct Mark { ismpc_a_handle* h; hipStream_t s; ~Mark() { h->last_stream = s; h->used = true; } } mark_{h, s};
     if (batch > h->prev_cap) {
-        if (h->prev) HIP_TRY_A(hipFreeAsync(h->prev, s));
+        HIP_TRY_A(grow_sync(h, s)); if (h->prev) HIP_TRY_A(hipFreeAsync(h->prev, s));
         h->prev = nullptr; h->prev_cap = 0;
         HIP_TRY_A(hipMallocAsync((void**)&h->prev, sizeof(ismpc_a_state) * (size_t)batch, s));
         h->prev_cap = batch;
@@ -1037,7 +1051,7 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
         };
         if (inst_dev && h->c.F > 3 && h->bucket_by_F && rl <= 4 && h->c.F <= 6) {
             if (batch > h->order_cap) {
-                if (h->order) HIP_TRY_A(hipFreeAsync(h->order, s));
+                HIP_TRY_A(grow_sync(h, s)); if (h->order) HIP_TRY_A(hipFreeAsync(h->order, s));
                 h->order = nullptr; h->order_cap = 0;
                 HIP_TRY_A(hipMallocAsync((void**)&h->order, sizeof(int) * (4 * (size_t)batch + 4), s));
                 h->order_cap = batch;
@@ -1056,7 +1070,7 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
             const bool resolve = h->precision == 1 && !h->defer_off;
             if (resolve) {
                 if (batch > h->defer_cap) {                  // stream-ordered growth, as the history
-                    if (h->defer_list) HIP_TRY_A(hipFreeAsync(h->defer_list, s));
+                    HIP_TRY_A(grow_sync(h, s)); if (h->defer_list) HIP_TRY_A(hipFreeAsync(h->defer_list, s));
                     h->defer_list = nullptr; h->defer_cap = 0;
                     HIP_TRY_A(hipMallocAsync((void**)&h->defer_list, sizeof(int) * 2 * (size_t)batch, s));
                     h->defer_cap = batch;
@@ -1069,7 +1083,10 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
                 // instantiation: one workgroup, usually nothing to do
                 ismpc_a::WaveLaunch W2 = WL;
                 W2.precision = 0; W2.work_counter = h->work_counter + 1; W2.order = h->defer_list; W2.count_ptr = h->work_counter + 2;
-                W2.order_is_qp = 1; W2.defer_list = nullptr; W2.defer_count = nullptr; W2.static_q = 0; W2.claim_chunk = 1; W2.grid_cap = 1;
+                W2.order_is_qp = 1; W2.defer_list = nullptr; W2.defer_count = nullptr; W2.static_q = 0; W2.claim_chunk = 1;
+                // usually nothing to do (one QP in 30 000 on the bench pushes), but harder pushes hand over hundreds: up to 64 workgroups
+                // (256 QPs at a time); a workgroup that finds the list empty exits after its prologue
+                W2.grid_cap = h->resolve_grid;
                 wrc = go(W2);
             }
         }
@@ -1096,6 +1113,17 @@ int ismpc_a_set_precision(ismpc_a_handle* h, int fp32)
     if (fp32 && (h->c.F < 3 || h->c.F > 6 || !h->use_wave)) return fail_a(-1, "the fp32 solve needs the structured kernel: 3 <= F <= 6");
     h->precision = fp32 ? 1 : 0; h->hist_valid = false;
     return 0;
+}
+
+int ismpc_a_last_deferred(ismpc_a_handle* h)
+{
+    if (!h) return fail_a(-1, "null handle");
+    if (!h->used || h->precision != 1 || h->defer_off) return 0;
+    ON_DEVICE_A(h);
+    int n = 0;
+    HIP_TRY_A(hipStreamSynchronize(h->last_stream));
+    HIP_TRY_A(hipMemcpy(&n, h->work_counter + 2, sizeof(int), hipMemcpyDeviceToHost));
+    return n;
 }
 
 int ismpc_a_set_warm_history(ismpc_a_handle* h, int enabled)
@@ -1151,6 +1179,7 @@ int ismpc_a_tick_feet_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* 
                                    ismpc_a_out* out_dev, double* feet_dev, void* stream)
 {
     if (!h || !out_dev || (batch > 0 && !feet_dev) || h->feet.rows == 0) return fail_a(-1, "feet: call ismpc_a_feet_init_device first and pass an output buffer");
+    ON_DEVICE_A(h);                                                 // the feet launch below runs on the handle's device too
     int rc = ismpc_a_tick_batch_device(h, batch, state_dev, push_dev, out_dev, stream);
     if (rc || batch == 0) return rc;
     hipLaunchKernelGGL(ismpc_a_feet_kernel, dim3((batch + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
@@ -1163,6 +1192,7 @@ int ismpc_a_rollout_feet_device(ismpc_a_handle* h, int batch, ismpc_a_state* sta
                                 double* feet_dev, void* stream)
 {
     if (!h || !out_traj_dev || batch < 0 || ticks < 0) return fail_a(-1, "bad argument");
+    ON_DEVICE_A(h);
     const bool keep = h->hist_ticks;
     h->hist_ticks = true; h->hist_valid = false;                     // closed loop: previous working set as the first guess
     int rc = 0;

@@ -478,7 +478,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             double bup = axis == 0 ? c.disp_forw : (c.disp_L / 2 + c.disp_L / 2);
             if (fc == 1 && r == 1) bup = axis == 0 ? c.disp_forw_dummy : (c.disp_L / 2 + c.disp_L / 2);
             khi = (R)bup; klo = (R)(-bup);                                       // f_1 - cur, f_r - f_{r-1}: symmetric in these coordinates
-            fr = (status & ISMPC_A_ST_BAD_INDEX) ? R(0) : (R)((fs[fc + r - 1] + off) - cur);
+            // (a lane beyond this instance's footstep count would read past the plan near its end: no load)
+            fr = ((status & ISMPC_A_ST_BAD_INDEX) || (PI && r > Fi)) ? R(0) : (R)((fs[fc + r - 1] + off) - cur);
             if (PI && r > Fi) { khi = R(INFINITY); klo = R(-INFINITY); fr = R(0); }   // beyond this instance's horizon: no variable, no row
         }
         const R knrm = (lane >= 2) ? sq * R(0.70710678118654752440) : sq;   // 1 / |K_r|_{H^-1}: |kvec_r|^2 = 2 (r >= 2) or 1
@@ -776,7 +777,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 const unsigned long long* hq = hist + (size_t)qp * 8;
                 unsigned long long any_ = 0ull;
 #pragma unroll
-                for (int k = 0; k < 2 * 4; ++k) any_ |= hq[k];
+                for (int k = 0; k < RL; ++k) any_ |= hq[k] | hq[4 + k];           // only the words the store below writes
                 have_guess = any_ != 0ull;
             }
             // Three phases share one Goldfarb-Idnani loop.  phase 0 (one-shot ticks): up to c.warm_gi rows enter one at a time

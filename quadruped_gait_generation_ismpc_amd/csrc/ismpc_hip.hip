@@ -1752,7 +1752,8 @@ struct ismpc_handle {
     ismpc_tick_in* st_in = nullptr; ismpc_tick_out* st_out = nullptr; int st_cap = 0;
     ismpc_tick_in* pin_in = nullptr; ismpc_tick_out* pin_out = nullptr;   // host-mapped staging for small batches (PIN_BATCH records)
     bool pin_off = false;
-    hipStream_t own_stream = nullptr;
+    hipStream_t own_stream = nullptr, own_stream2 = nullptr;   // the second one: odd chunks of the pipelined host path
+    int host_chunks = 4;                                        // ISMPC_HOST_CHUNKS: chunks of a pipelined host call (0 / 1: never pipeline)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false; bool timed_pending = false; double last_ms = 0.0;
     int force_waves = 0;      // dense path: 4, 8 or 16 wavefronts per workgroup (0 = 16)
@@ -1766,6 +1767,8 @@ struct ismpc_handle {
                               // there, slower from 3 072 on), 16 otherwise; the tables exist in both layouts
     const double* vqT32 = nullptr; const double* tzgT32 = nullptr;
     bool kernel_rollout = true;   // closed loops run inside one launch (ismpc_rollout_quad); ISMPC_ROLLOUT=host: one launch per tick
+    hipStream_t last_stream = nullptr; bool used = false;   // stream of the previous launch: zmark / zstop outlive a call and are re-allocated
+                                                            // only after that stream has drained (grow_sync)
 };
 
 namespace {
@@ -1797,24 +1800,45 @@ int quad_R(int N, int lpi)
     if (lpi == 16) { if (RQ == 4) X(4, 16, 1); else if (RQ == 7) X(7, 16, 2); else X(8, 16, 2); } \
     else           { if (RQ == 8) X(8, 8, 1);   else if (RQ == 13) X(13, 8, 2); else X(16, 8, 2); }
 
+// Scratch that outlives the call that allocated it (zmark, zstop) is used by later calls on whatever stream those pass: before
+// it is re-allocated on stream `s`, the previous launch's stream -- if it is another one -- is drained.
+hipError_t grow_sync(ismpc_handle* h, hipStream_t s)
+{
+    if (h->used && h->last_stream != s) return hipStreamSynchronize(h->last_stream);
+    return hipSuccess;
+}
+bool host_is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+struct StreamMark { ismpc_handle* h; hipStream_t s; ~StreamMark() { h->last_stream = s; h->used = true; } };
+
+// zoff / zcap / lid: the chunks of ONE pipelined host call (ismpc_solve_batch) run concurrently on two streams; each owns the slice
+// [zoff, zoff + batch) of the fallback marks (zcap = the whole call's instances) and all share one launch id, so that a chunk's
+// fallback launch is never switched off by another chunk's deferral (zflag holds the id of the last launch that deferred).
 int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* state, ismpc_tick_out* out,
-           double* u_traj, int rollout_frame, hipStream_t s)
+           double* u_traj, int rollout_frame, hipStream_t s, int zoff = 0, int zcap = 0, int lid_shared = 0)
 {
     if (batch <= 0) return ISMPC_OK;
+    StreamMark mark_{h, s};
+    if (zcap < batch) zcap = batch;
     const int R = (h->c.N + 63) / 64;
     if (!h->dense_path) {
         // fast path: wavefront per instance, 4 per workgroup; then the (normally empty) inequality fallback
         const dim3 grid((batch + 3) / 4), block(256);
-        if (h->z_fallback && batch > h->zmark_cap) {
+        if (h->z_fallback && zcap > h->zmark_cap) {
             // stream-ordered growth (no device-wide synchronisation inside an asynchronous entry point); callers that
             // capture graphs size it beforehand with ismpc_reserve
+            HIP_TRY(grow_sync(h, s));
             if (h->zmark) HIP_TRY(hipFreeAsync(h->zmark, s));
             h->zmark = nullptr; h->zmark_cap = 0;
-            HIP_TRY(hipMallocAsync((void**)&h->zmark, (size_t)batch, s));
-            h->zmark_cap = batch;
+            HIP_TRY(hipMallocAsync((void**)&h->zmark, (size_t)zcap, s));
+            h->zmark_cap = zcap;
         }
-        unsigned char* zm = h->z_fallback ? h->zmark : nullptr;
-        const int lid = ++h->launch_id;
+        unsigned char* zm = h->z_fallback ? h->zmark + zoff : nullptr;
+        const int lid = lid_shared > 0 ? lid_shared : ++h->launch_id;
         const dim3 fgrid(std::min((batch + 3) / 4, 64));
         // default for N <= 128: several instances per wavefront (ismpc_tick_quad); ISMPC_PATH=wave keeps one per wavefront
         if (h->quad_path && h->c.N <= 128) {
@@ -2003,7 +2027,9 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     }
     c.flat = t.flat ? 1 : 0;
     if (rc != ISMPC_OK) { ismpc_destroy(h); return rc; }
-    if (hipStreamCreate(&h->own_stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
+    if (const char* hc = std::getenv("ISMPC_HOST_CHUNKS")) h->host_chunks = std::max(0, std::min(std::atoi(hc), 64));
+    if (hipStreamCreateWithFlags(&h->own_stream2, hipStreamNonBlocking) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_NO_DEVICE, "stream creation failed"); }
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
         hipEventCreate(&h->ev1) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_NO_DEVICE, "stream/event creation failed"); }
     *out = h;
     return ISMPC_OK;
@@ -2023,6 +2049,7 @@ void ismpc_destroy(ismpc_handle* h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->own_stream2) (void)hipStreamDestroy(h->own_stream2);
     delete h;
 }
 
@@ -2079,6 +2106,31 @@ int ismpc_solve_batch(ismpc_handle* h, int batch, const ismpc_tick_in* in_host, 
         HIP_TRY(hipMalloc((void**)&h->st_out, sizeof(ismpc_tick_out) * (size_t)batch));
         h->st_cap = batch;
     }
+    // Large batches in page-locked caller buffers (hipHostMalloc / hipHostRegister / ismpc_host_alloc / ismpc_host_register): the
+    // batch is cut into chunks that alternate between two streams, so that copy-in of chunk k+1, the kernel of chunk k and
+    // copy-out of chunk k-1 overlap (the two DMA directions run on separate engines).  Chunks stay above LPI32_BATCH
+    // instances: every chunk runs the kernel shape the whole batch would, records are bit-identical to the one-launch path.
+    // Pageable buffers cannot overlap (the runtime stages them synchronously) and take the serial path below.
+    constexpr int PIPE_MIN_CHUNK = 4096;
+    if (h->host_chunks >= 2 && !h->dense_path && batch >= 2 * PIPE_MIN_CHUNK && host_is_pinned(in_host) && host_is_pinned(out_host)) {
+        const int nchunk = std::min(h->host_chunks, batch / PIPE_MIN_CHUNK);
+        const int per = (((batch + nchunk - 1) / nchunk) + 63) & ~63;
+        const int lid = ++h->launch_id;
+        hipStream_t ss[2] = { h->own_stream, h->own_stream2 };
+        if (h->timing) HIP_TRY(hipEventRecord(h->ev0, ss[0]));
+        for (int c = 0, off = 0; off < batch; ++c, off += per) {
+            const int n = std::min(per, batch - off);
+            hipStream_t s = ss[c & 1];
+            HIP_TRY(hipMemcpyAsync(h->st_in + off, in_host + off, sizeof(ismpc_tick_in) * (size_t)n, hipMemcpyHostToDevice, s));
+            const int rc = launch(h, n, h->st_in + off, nullptr, h->st_out + off, nullptr, -1, s, off, batch, lid);
+            if (rc != ISMPC_OK) { (void)hipStreamSynchronize(ss[0]); (void)hipStreamSynchronize(ss[1]); return rc; }
+            HIP_TRY(hipMemcpyAsync(out_host + off, h->st_out + off, sizeof(ismpc_tick_out) * (size_t)n, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(ss[1]));
+        if (h->timing) { HIP_TRY(hipEventRecord(h->ev1, ss[0])); h->timed_pending = true; }
+        HIP_TRY(hipStreamSynchronize(ss[0]));
+        return ISMPC_OK;
+    }
     hipStream_t s = h->own_stream;
     HIP_TRY(hipMemcpyAsync(h->st_in, in_host, sizeof(ismpc_tick_in) * (size_t)batch, hipMemcpyHostToDevice, s));
     int rc = ismpc_solve_batch_device(h, batch, h->st_in, h->st_out, nullptr, s);
@@ -2094,6 +2146,7 @@ int ismpc_rollout_device(ismpc_handle* h, int batch, ismpc_tick_in* state_dev, i
     if (!h || batch < 0 || ticks < 0 || first_frame < 0 || (batch > 0 && !state_dev)) return fail(ISMPC_E_INVALID, "bad argument");
     ON_DEVICE(h);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    StreamMark mark_{h, s};
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
     if (batch > 0 && ticks > 0 && h->kernel_rollout && !h->dense_path && h->quad_path && h->c.N <= 128 && h->z_fallback) {
         // the whole closed loop in ONE launch: state in registers, one trajectory record per tick (ismpc_rollout_quad)
@@ -2104,6 +2157,7 @@ int ismpc_rollout_device(ismpc_handle* h, int batch, ismpc_tick_in* state_dev, i
         const int waves = (batch * lpi + 63) / 64;
         const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
         if (batch > h->zstop_cap) {                       // stream-ordered growth, as zmark (ismpc_reserve sizes it beforehand)
+            HIP_TRY(grow_sync(h, s));
             if (h->zstop) HIP_TRY(hipFreeAsync(h->zstop, s));
             h->zstop = nullptr; h->zstop_cap = 0;
             HIP_TRY(hipMallocAsync((void**)&h->zstop, sizeof(int) * (size_t)batch, s));
@@ -2124,6 +2178,33 @@ int ismpc_rollout_device(ismpc_handle* h, int batch, ismpc_tick_in* state_dev, i
         }
     }
     if (h->timing) { HIP_TRY(hipEventRecord(h->ev1, s)); h->timed_pending = true; }
+    return ISMPC_OK;
+}
+
+// Page-locked host memory for callers without HIP headers (the pipelined ismpc_solve_batch needs it on both sides).
+int ismpc_host_alloc(size_t bytes, void** out)
+{
+    if (!out || bytes == 0) return fail(ISMPC_E_INVALID, "bad argument");
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(ISMPC_E_ALLOC, "hipHostMalloc failed"); }
+    return ISMPC_OK;
+}
+int ismpc_host_free(void* p)
+{
+    if (!p) return ISMPC_OK;
+    HIP_TRY(hipHostFree(p));
+    return ISMPC_OK;
+}
+int ismpc_host_register(void* p, size_t bytes)
+{
+    if (!p || bytes == 0) return fail(ISMPC_E_INVALID, "bad argument");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return ISMPC_OK;
+}
+int ismpc_host_unregister(void* p)
+{
+    if (!p) return fail(ISMPC_E_INVALID, "bad argument");
+    HIP_TRY(hipHostUnregister(p));
     return ISMPC_OK;
 }
 

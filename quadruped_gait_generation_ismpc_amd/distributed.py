@@ -17,13 +17,14 @@ def shard_range(global_batch, rank, world):
     return first, count
 
 
-def gather_records(local_u8, world=None, out=None, group=None, counts=None):
+def gather_records(local_u8, world=None, out=None, group=None, counts=None, force=False):
     """All-gather per-rank record blocks [count_r, rec] (uint8) into [sum count_r, rec] in rank order.
     Equal shard sizes take the single fused all_gather_into_tensor; ragged ones pad to the largest.
     `counts` (per-rank shard sizes, e.g. from shard_range) skips the size exchange: with it the call
-    is exactly ONE collective."""
+    is exactly ONE collective.  A world of one returns the input unless `force` (then the collective runs over the
+    one-rank group: communicator and stream order are exercised, no bytes leave the GPU)."""
     world = world if world is not None else dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return local_u8
     n_local = int(local_u8.shape[0])
     if counts is None:

@@ -37,7 +37,8 @@ EXPORTS_A = ["ismpc_a_params_default", "ismpc_a_gait_default", "ismpc_a_plan", "
              "ismpc_a_initial_state", "ismpc_a_tick_batch_device", "ismpc_a_rollout_device", "ismpc_a_last_error",
              "ismpc_a_feet_rows", "ismpc_a_feet_init_device", "ismpc_a_tick_feet_batch_device",
              "ismpc_a_rollout_feet_device", "ismpc_a_foot_trajectories", "ismpc_a_write_trajectory_txt",
-             "ismpc_a_add_plan", "ismpc_a_tick_batch_inst_device", "ismpc_a_rollout_inst_device", "ismpc_a_set_warm_history", "ismpc_a_reserve", "ismpc_a_set_precision"]
+             "ismpc_a_add_plan", "ismpc_a_tick_batch_inst_device", "ismpc_a_rollout_inst_device", "ismpc_a_set_warm_history", "ismpc_a_reserve", "ismpc_a_set_precision",
+             "ismpc_a_last_deferred"]
 HAVE_F32 = True        # the QP solve also exists in fp32 (GaitGenerator(..., precision="f32"))
 FEET_PAD = 8
 
@@ -70,6 +71,7 @@ def _l():
         lib.ismpc_a_rollout_inst_device.argtypes = [vp, ci, vp, vp, ci, vp, vp]; lib.ismpc_a_rollout_inst_device.restype = ci
         lib.ismpc_a_reserve.argtypes = [vp, ci]; lib.ismpc_a_reserve.restype = ci
         lib.ismpc_a_set_precision.argtypes = [vp, ci]; lib.ismpc_a_set_precision.restype = ci
+        lib.ismpc_a_last_deferred.argtypes = [vp]; lib.ismpc_a_last_deferred.restype = ci
         _bound = True
     return lib
 
@@ -198,6 +200,13 @@ class GaitGenerator:
         if rc != 0:
             raise IsmpcAError(_l().ismpc_a_last_error().decode())
         return traj
+
+    def last_deferred(self):
+        """QPs the last fp32 launch handed to the fp64 re-solve launch behind it (synchronises)."""
+        n = _l().ismpc_a_last_deferred(self._h)
+        if n < 0:
+            raise IsmpcAError(_l().ismpc_a_last_error().decode())
+        return n
 
     def set_warm_history(self, enabled=True):
         """Caller-driven tick loops: start every QP from the working set the same instance had in the previous call."""

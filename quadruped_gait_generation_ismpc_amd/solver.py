@@ -124,9 +124,13 @@ class MPCSolver:
         return nxt
 
     # ---- batch, host buffers ----
-    def solve_batch(self, tick_in):
+    def solve_batch(self, tick_in, out=None):
+        """Host records in, host records out (ismpc_solve_batch).  With both arrays in page-locked memory (PinnedRecords) large
+        batches run as a copy / kernel / copy pipeline; `out` is allocated (pageable) when not given."""
         tick_in = np.ascontiguousarray(tick_in, dtype=TICK_IN).reshape(-1)
-        out = np.zeros(tick_in.shape[0], dtype=TICK_OUT)
+        if out is None:
+            out = np.zeros(tick_in.shape[0], dtype=TICK_OUT)
+        assert out.dtype == TICK_OUT and out.flags.c_contiguous and out.shape == (tick_in.shape[0],)
         self._check(self._lib.ismpc_solve_batch(self._h, tick_in.shape[0], tick_in.ctypes.data_as(C.c_void_p),
                                                 out.ctypes.data_as(C.c_void_p)))
         return out

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 --pmc counter_collection CSVs of scripts/pmc.sh / scripts/pmc_a.sh into the JSON summaries kept
+"""Turns the rocprofv3 --pmc counter_collection CSVs of scripts/profile_r03.sh into the JSON summaries kept
 under profiles/ (mean per launch of one kernel; HBM bytes with the gfx950 correction MI355X_MICROARCH.md prescribes:
 FETCH_SIZE counts 32 B units... reported in KiB-like units of 1 KB here, doubled for wide coalesced reads).
 usage: python scripts/pmc_summary.py <dir with one sub-directory per pass> <kernel name substring> <out.json> [key=value ...]"""
@@ -39,6 +39,16 @@ if "TA_TA_BUSY_sum" in mean and "GRBM_GUI_ACTIVE" in mean and mean["GRBM_GUI_ACT
         d["l1_line_accesses_per_load_wavefront"] = mean["TCP_TOTAL_CACHE_ACCESSES_sum"] / mean["TA_FLAT_LOAD_WAVEFRONTS_sum"]
 if "TCC_HIT_sum" in mean and "TCC_MISS_sum" in mean:
     d["l2_hit_rate"] = mean["TCC_HIT_sum"] / max(1.0, mean["TCC_HIT_sum"] + mean["TCC_MISS_sum"])
+# executed floating-point work: wave-instructions by type x 64 lanes (what the pipe spends whatever the exec mask), FMA = 2 flop
+for T in ("F64", "F32"):
+    ks = [f"SQ_INSTS_VALU_{o}_{T}" for o in ("ADD", "MUL", "FMA", "TRANS")]
+    if all(k in mean for k in ks):
+        a, mu, f, t = (mean[k] for k in ks)
+        d[f"fp_insts_{T.lower()}_per_launch"] = a + mu + f + t
+        d[f"flops_{T.lower()}_per_launch"] = 64.0 * (a + mu + t + 2.0 * f)
+if "SQ_INSTS_VALU" in mean:
+    fp = d.get("fp_insts_f64_per_launch", 0.0) + d.get("fp_insts_f32_per_launch", 0.0)
+    if fp > 0: d["fp_share_of_valu_insts"] = fp / mean["SQ_INSTS_VALU"]
 res["derived"] = d
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(d, indent=1))

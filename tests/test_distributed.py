@@ -118,3 +118,31 @@ def test_double_buffered_gather_pipeline_order(built_libs):
     for p in procs:
         p.join(60); assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _run_bench(*argv):
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ISMPC_BENCH_CHILD")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True, timeout=120, env=env, cwd=root)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, lines, r.stderr
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus N` as typed: the parent starts N rank processes with the variables torch.distributed.run sets,
+    forwards rank 0's line and exits 0 (no GPU is touched by the self-test ranks)."""
+    rc, lines, err = _run_bench("--gpus", "4", "--launcher-selftest", "-1")
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["world"] == 4 and lines[0]["rank"] == 0 and lines[0]["master"] == "127.0.0.1" and lines[0]["port"] > 0
+    rc, lines, err = _run_bench("--gpus", "1", "--spawn", "--launcher-selftest", "-1")
+    assert rc == 0 and lines[0]["world"] == 1, err
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """One rank exits non-zero: the others (which would wait in a collective for ever) are stopped and the launcher fails."""
+    import time
+    t0 = time.time()
+    rc, lines, err = _run_bench("--gpus", "3", "--launcher-selftest", "2")
+    assert rc == 7 and "rank 2 exited" in err
+    assert time.time() - t0 < 25                       # the surviving ranks (sleeping 30 s) were stopped, not waited for

@@ -338,7 +338,11 @@ def test_full_size_properties(q, O):
         pick = np.random.default_rng(batch).choice(batch, 192, replace=False)
         ref, info = O.Oracle(O.default_params(N)).solve(tin[pick])
         assert_parity(q, out[pick], ref)
-        assert (out["status"][pick] == ref["status"]).mean() > 0.98
+        # status equality by the rule of test_against_oracle_seeded: the only admissible difference is a horizontal QP within
+        # 1e-9 (relative) of its feasibility boundary, which qpOASES' own termination test may classify either way
+        for b in np.where(out["status"][pick] != ref["status"])[0]:
+            assert ((out["status"][pick][b] ^ ref["status"][b]) & ~(q.ST_X_INFEASIBLE | q.ST_Y_INFEASIBLE)) == 0
+            assert _on_feasibility_boundary(q, N, tin[pick[b]], band=1e-9), (batch, pick[b], out["status"][pick][b], ref["status"][b])
 
 
 @pytest.mark.parametrize("batch", [8192, 65536])

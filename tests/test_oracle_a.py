@@ -19,7 +19,8 @@ from oracle import oracle_a as A
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 META = json.load(open(os.path.join(GOLDEN, "formA_matlab_meta.json")))
 TOL_COM = {"trot": 3e-6, "walk": 5e-5}
-# ticks replayed in the regular suite (the whole 2000-tick files: test_full_fixture_replay, run with -m slow)
+# ticks replayed per fixture in test_matlab_fixture_replay (the whole files: test_trot_15cm_file_is_two_appended_runs and
+# test_foot_files_replay below, and every file on the device in tests/test_gpu_formulation_a.py)
 TICKS = {"walk_phi0": 700, "walk_phipi4": 700, "walk_phipi2": 700, "trot_phi0": 330, "trot_phipi4": 330,
          "trot_phipi4_15": 330, "trot_phipi2": 330}
 
@@ -49,6 +50,20 @@ def test_matlab_fixture_replay(name, built_libs):
     # the gait actually steps: footstep counter advances every `step` ticks (quad_walk_no_plots.m:522)
     step = 50 if m["gait"] == "walk" else 80
     assert np.array_equal(np.where(outs["stepped"] == 1)[0] + 2, np.arange(1, ticks // step + 1) * step)
+
+
+def test_trot_15cm_file_is_two_appended_runs(built_libs):
+    """trotting/phipi4/15cm holds 3 200 rows because the script opens every output file in append mode
+    (trotting/quad_as_bip_no_plots.m:105-114, fopen(..., 'a+')): it is a 1 200-tick run followed by a fresh 2 000-tick run from
+    the same initial state.  Both runs are known answers for ONE 2 000-tick replay: rows 0..1199 against its first 1 200
+    ticks, rows 1200..3199 against all of it."""
+    outs, z, m = replay("trot_phipi4_15", 2000)
+    com, vel = z["com"], z["vel"]
+    assert com.shape == (3200, 3) and np.array_equal(com[1200], com[0]) and np.array_equal(com[1200:2400], com[:1200])
+    assert (outs["rv"] == 0).all()
+    for rows, n in ((slice(0, 1200), 1200), (slice(1200, 3200), 2000)):
+        assert np.abs(outs["com_before"][:n] - com[rows, :2]).max() <= TOL_COM["trot"]
+        assert np.abs(outs["vel_after"][:n] - vel[rows, :2]).max() <= 1e-4
 
 
 @pytest.mark.parametrize("name", ["walk_phipi4", "trot_phipi4"])
@@ -102,10 +117,11 @@ def test_mapping_overflow_is_reported(built_libs):
 FOOT_TOL = {"trot": 3e-6, "walk": 5e-5}
 
 
-@pytest.mark.parametrize("name", ["trot_phipi4", "trot_phipi2", "walk_phipi4", "walk_phi0", "walk_phipi2"])
+@pytest.mark.parametrize("name", sorted(META))
 def test_foot_files_replay(name, built_libs):
-    """the swing-foot re-placement QPs + foot trajectory writer of the scripts, against the checked-in
-    foot_{fl,fr,rl,rr}_*.txt (2000 rows each)."""
+    """the swing-foot re-placement QPs + foot trajectory writer of the scripts, against every checked-in
+    foot_{fl,fr,rl,rr}_*.txt (2000 rows each; trotting/phi0 holds two of the four files, trotting/phipi4/15cm the feet of
+    its 2 000-tick run)."""
     m = META[name]
     kind = A.WALK if m["gait"] == "walk" else A.TROT
     sim = A.SimA(A.gait(kind, m["phi"], m["disp_A"]), A.params(kind), backend="gi")
@@ -114,7 +130,11 @@ def test_foot_files_replay(name, built_libs):
     assert (outs["rv"] == 0).all()
     tr = sim.foot_trajectories(2000)
     z = np.load(os.path.join(GOLDEN, f"formA_matlab_{name}.npz"))
+    have = [ft for ft in ("fl", "fr", "rl", "rr") if f"foot_{ft}" in z.files]
+    assert len(have) == (2 if name == "trot_phi0" else 4)
     for k, ft in enumerate(("fl", "fr", "rl", "rr")):
+        if ft not in have:
+            continue
         fix = z[f"foot_{ft}"]
         assert fix.shape == (2000, 3)
         assert np.abs(tr[k] - fix).max() <= FOOT_TOL[m["gait"]], (ft, np.abs(tr[k] - fix).max())
