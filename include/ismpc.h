@@ -122,19 +122,20 @@ void ismpc_destroy(ismpc_handle* h);
 /* One MPCSolver::solve per instance, `batch` independent instances.
  * Host pointers; copies in, runs, copies out, returns when done
  * (Controller.cpp:346-348: by value in, by value out).
- * Batches of >= 8 192 records in PAGE-LOCKED buffers (hipHostMalloc,
- * hipHostRegister, or the ismpc_host_* helpers below) run as a pipeline of
- * chunks on two streams: copy-in of chunk k+1, the kernel of chunk k and
- * copy-out of chunk k-1 overlap; results are bit-identical to the
- * device-pointer entry point.  Pageable buffers work too, serially (the HIP
- * runtime stages them), and batches of <= 64 records are read and written by
- * the kernel in place (host memory mapped into the device).                */
+ * Records in PAGE-LOCKED buffers (hipHostMalloc, hipHostRegister, or the
+ * ismpc_host_* helpers below) are read and written by the kernel IN PLACE
+ * over PCIe (zero copy: no staging, no DMA submissions; reads and writes use
+ * the two directions of the link at once); results are bit-identical to the
+ * device-pointer entry point.  Pageable buffers work too: they are staged
+ * through device memory (the HIP runtime pins them chunk by chunk), and
+ * batches of <= 64 records go through a small mapped staging block.        */
 int ismpc_solve_batch(ismpc_handle* h, int batch,
                       const ismpc_tick_in* in_host, ismpc_tick_out* out_host);
 
 /* Page-locked host memory without HIP headers on the caller's side: allocate
  * record buffers with ismpc_host_alloc, or pin existing ones for as long as
- * they live with ismpc_host_register (unregister BEFORE freeing them).       */
+ * they live with ismpc_host_register (unregister BEFORE freeing them).  The
+ * kernel's writes are visible to the host when ismpc_solve_batch returns.    */
 int ismpc_host_alloc(size_t bytes, void** out);
 int ismpc_host_free(void* p);
 int ismpc_host_register(void* p, size_t bytes);

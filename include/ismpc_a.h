@@ -168,6 +168,19 @@ int ismpc_a_tick_feet_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* 
                                    ismpc_a_out* out_dev, double* feet_dev, void* stream);
 int ismpc_a_rollout_feet_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, int ticks,
                                 ismpc_a_out* out_traj_dev, double* feet_dev, void* stream);
+/* The same for batches with per-instance gait parameters (ismpc_a_inst; BASELINE configs[4]): instance b follows the foot
+ * rules of its base plan inst[b].plan (trot or walk, heading, lateral limits) and starts from that plan's foot_plan.
+ * gaits: one record per base plan of the handle, in the order ismpc_a_create / ismpc_a_add_plan registered them;
+ * foot_plans_host: nplans x rows x 8 doubles.  The scripts re-run once per parameter value
+ * (trotting/quad_as_bip_no_plots.m:332-426 + compute_two_feet1.m:1-56, walking/quad_walk_no_plots.m:336-504 +
+ * compute_one_feet_walk.m:84-140); the foot files of instance b are ismpc_a_foot_trajectories on its rows of feet_dev
+ * with its own step_duration.                                                                                          */
+int ismpc_a_feet_init_inst_device(ismpc_a_handle* h, const ismpc_a_gait* gaits, const double* foot_plans_host, int rows,
+                                  int nplans, int batch, const ismpc_a_inst* inst_dev, double* feet_dev, void* stream);
+int ismpc_a_tick_feet_batch_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev,
+                                        const double* push_dev, ismpc_a_out* out_dev, double* feet_dev, void* stream);
+int ismpc_a_rollout_feet_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev,
+                                     int ticks, ismpc_a_out* out_traj_dev, double* feet_dev, void* stream);
 /* Host: the four foot files of one instance.  foot_plan: rows x 8 (as left by the rollout); dst: 4 x n x 3 in the
  * order fl, fr, rl, rr with n = (sim_duration / step) * step rows; returns n. */
 int ismpc_a_foot_trajectories(const ismpc_a_gait* g, int step, const double* foot_plan, int rows, int sim_duration, double* dst);

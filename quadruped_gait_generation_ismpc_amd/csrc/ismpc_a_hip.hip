@@ -524,6 +524,7 @@ void ismpc_a_tick_kernel(const DevA c, const ismpc_a_state* __restrict__ state_i
 // minimiser is the projection of the target on the box).  trotting/quad_as_bip_no_plots.m:332-426 + compute_two_feet1.m,
 // walking/quad_walk_no_plots.m:336-504 + compute_one_feet_walk.m:84-140.
 struct FeetParams { int gait, rows; double phi, disp_i, disp_o, disp_forw; };
+struct FeetParamsSet { FeetParams p[4]; };           // per base plan (ismpc_a_inst.plan): Monte-Carlo batches mix trot and walk instances
 
 __device__ __forceinline__ void fixed_diagonal(double fx1, double fy1, double fx2, double fy2, double zx, double zy,
                                                double& m, double& dx, double& dy)
@@ -535,12 +536,15 @@ __device__ __forceinline__ void fixed_diagonal(double fx1, double fy1, double fx
 }
 __device__ __forceinline__ double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ void ismpc_a_feet_kernel(const FeetParams fpz, const ismpc_a_state* __restrict__ prev, const ismpc_a_out* __restrict__ out,
-                                    double* __restrict__ feet, int batch)
+__global__ void ismpc_a_feet_kernel(const FeetParamsSet fset, const ismpc_a_inst* __restrict__ inst, int nplans, const ismpc_a_state* __restrict__ prev,
+                                    const ismpc_a_out* __restrict__ out, double* __restrict__ feet, int batch)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     if (out[b].status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) return;
+    int pl = inst ? inst[b].plan : 0;                            // per-instance gait parameters: the foot rules of the instance's base plan
+    if (pl < 0 || pl >= nplans) return;
+    const FeetParams fpz = fset.p[pl];
     const int fc = prev[b].fc;                                   // the fsCounter this tick ran with
     if (fc < 1 || fc + 8 >= fpz.rows) return;
     double* fp = feet + (size_t)b * fpz.rows * 8;
@@ -601,6 +605,16 @@ __global__ void ismpc_a_feet_fill(const double* __restrict__ base, double* __res
 {
     const size_t n = (size_t)batch * rows * 8;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) feet[e] = base[e % ((size_t)rows * 8)];
+}
+// every instance starts from the foot plan of ITS base plan (base: nplans x rows x 8)
+__global__ void ismpc_a_feet_fill_inst(const double* __restrict__ base, const ismpc_a_inst* __restrict__ inst, int nplans, double* __restrict__ feet, int rows, int batch)
+{
+    const size_t per = (size_t)rows * 8, n = (size_t)batch * per;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = e / per;
+        int pl = inst[b].plan; if (pl < 0 || pl >= nplans) pl = 0;
+        feet[e] = base[(size_t)pl * per + (e - b * per)];
+    }
 }
 
 // Per-instance gait parameters: the instances of a batch differ in their footstep count F_i (3..6), and a QP costs what the
@@ -683,6 +697,7 @@ struct ismpc_a_handle {
     int device = 0, slots = 0;
     ismpc_a_state* prev = nullptr; int prev_cap = 0;     // copy of the state the tick reads
     FeetParams feet{}; double* feet_base = nullptr;     // swing-foot QPs (ismpc_a_feet_init_device)
+    FeetParamsSet feet_set{}; int feet_plans = 0;        // ... and per base plan (ismpc_a_feet_init_inst_device)
     bool use_wave = true; int wave_blocks = 0;           // structured wavefront-per-QP kernel (default) vs workgroup-per-QP
     int cus = 0, wave_occ[16] = {0};                     // resident workgroups per CU of the wave kernels ([F - 3][precision x per-instance])
     int* order = nullptr; int order_cap = 0;             // per-instance launches: instance lists by footstep count (4 x cap) + 4 counters
@@ -1175,30 +1190,81 @@ int ismpc_a_feet_init_device(ismpc_a_handle* h, const ismpc_a_gait* g, const dou
     return 0;
 }
 
+static int tick_feet(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev, const double* push_dev,
+                     ismpc_a_out* out_dev, double* feet_dev, void* stream, int history = -1)
+{
+    if (!h || !out_dev || (batch > 0 && !feet_dev) || h->feet.rows == 0) return fail_a(-1, "feet: call ismpc_a_feet_init_device first and pass an output buffer");
+    if (inst_dev && h->feet_plans == 0) return fail_a(-1, "feet: per-instance batches need ismpc_a_feet_init_inst_device");
+    ON_DEVICE_A(h);                                                 // the feet launch below runs on the handle's device too
+    int rc = tick_launch(h, batch, state_dev, inst_dev, push_dev, out_dev, stream, history);
+    if (rc || batch == 0) return rc;
+    FeetParamsSet fs = h->feet_set;
+    if (!inst_dev) fs.p[0] = h->feet;
+    hipLaunchKernelGGL(ismpc_a_feet_kernel, dim3((batch + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       fs, inst_dev, inst_dev ? h->feet_plans : 1, (const ismpc_a_state*)h->prev, (const ismpc_a_out*)out_dev, feet_dev, batch);
+    HIP_TRY_A(hipGetLastError());
+    return 0;
+}
+
 int ismpc_a_tick_feet_batch_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const double* push_dev,
                                    ismpc_a_out* out_dev, double* feet_dev, void* stream)
 {
-    if (!h || !out_dev || (batch > 0 && !feet_dev) || h->feet.rows == 0) return fail_a(-1, "feet: call ismpc_a_feet_init_device first and pass an output buffer");
-    ON_DEVICE_A(h);                                                 // the feet launch below runs on the handle's device too
-    int rc = ismpc_a_tick_batch_device(h, batch, state_dev, push_dev, out_dev, stream);
-    if (rc || batch == 0) return rc;
-    hipLaunchKernelGGL(ismpc_a_feet_kernel, dim3((batch + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       h->feet, (const ismpc_a_state*)h->prev, (const ismpc_a_out*)out_dev, feet_dev, batch);
-    HIP_TRY_A(hipGetLastError());
-    return 0;
+    return tick_feet(h, batch, state_dev, nullptr, push_dev, out_dev, feet_dev, stream);
 }
 
 int ismpc_a_rollout_feet_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, int ticks, ismpc_a_out* out_traj_dev,
                                 double* feet_dev, void* stream)
 {
     if (!h || !out_traj_dev || batch < 0 || ticks < 0) return fail_a(-1, "bad argument");
+    int rc = 0;                                                      // closed loop: previous working set as the first guess
+    for (int t = 0; t < ticks && !rc; ++t)
+        rc = tick_feet(h, batch, state_dev, nullptr, nullptr, out_traj_dev + (size_t)t * batch, feet_dev, stream, t == 0 ? 1 : 2);
+    return rc;
+}
+
+// Per-instance gait parameters (ismpc_a_inst): instance b follows the foot rules and starts from the foot plan of its base plan.
+int ismpc_a_feet_init_inst_device(ismpc_a_handle* h, const ismpc_a_gait* gaits, const double* foot_plans_host, int rows, int nplans,
+                                  int batch, const ismpc_a_inst* inst_dev, double* feet_dev, void* stream)
+{
+    if (!h || !gaits || !foot_plans_host || rows < 2 || nplans < 1 || nplans > 4 || batch < 0 || (batch > 0 && (!feet_dev || !inst_dev)))
+        return fail_a(-1, "bad argument");
+    if (nplans != h->c.nplans) return fail_a(-1, "feet: one gait record and one foot plan per base plan of the handle (ismpc_a_create + ismpc_a_add_plan)");
     ON_DEVICE_A(h);
-    const bool keep = h->hist_ticks;
-    h->hist_ticks = true; h->hist_valid = false;                     // closed loop: previous working set as the first guess
+    const int rp = rows + 8;                                       // the walk script writes rows fc+1 .. fc+8
+    std::vector<double> base((size_t)nplans * rp * 8);
+    for (int k = 0; k < nplans; ++k)
+        for (int r = 0; r < rp; ++r)
+            std::memcpy(&base[((size_t)k * rp + r) * 8], foot_plans_host + ((size_t)k * rows + std::min(r, rows - 1)) * 8, 64);
+    if (h->feet_base) { (void)hipFree(h->feet_base); h->feet_base = nullptr; }
+    HIP_TRY_A(hipMalloc((void**)&h->feet_base, base.size() * sizeof(double)));
+    HIP_TRY_A(hipMemcpy(h->feet_base, base.data(), base.size() * sizeof(double), hipMemcpyHostToDevice));
+    for (int k = 0; k < nplans; ++k) {
+        FeetParams& f = h->feet_set.p[k];
+        f.gait = gaits[k].gait; f.rows = rp; f.phi = gaits[k].phi; f.disp_i = gaits[k].disp_i; f.disp_o = gaits[k].disp_o; f.disp_forw = gaits[k].disp_forw;
+    }
+    h->feet_plans = nplans; h->feet = h->feet_set.p[0];
+    if (batch > 0) {
+        hipLaunchKernelGGL(ismpc_a_feet_fill_inst, dim3(std::min(1024, (int)(((size_t)batch * rp * 8 + 255) / 256))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           (const double*)h->feet_base, inst_dev, nplans, feet_dev, rp, batch);
+        HIP_TRY_A(hipGetLastError());
+    }
+    return 0;
+}
+
+int ismpc_a_tick_feet_batch_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev, const double* push_dev,
+                                        ismpc_a_out* out_dev, double* feet_dev, void* stream)
+{
+    if (batch > 0 && !inst_dev) return fail_a(-1, "null per-instance parameter array");
+    return tick_feet(h, batch, state_dev, inst_dev, push_dev, out_dev, feet_dev, stream);
+}
+
+int ismpc_a_rollout_feet_inst_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, const ismpc_a_inst* inst_dev, int ticks,
+                                     ismpc_a_out* out_traj_dev, double* feet_dev, void* stream)
+{
+    if (!h || !out_traj_dev || batch < 0 || ticks < 0 || (batch > 0 && !inst_dev)) return fail_a(-1, "bad argument");
     int rc = 0;
     for (int t = 0; t < ticks && !rc; ++t)
-        rc = ismpc_a_tick_feet_batch_device(h, batch, state_dev, nullptr, out_traj_dev + (size_t)t * batch, feet_dev, stream);
-    h->hist_ticks = keep; h->hist_valid = false;
+        rc = tick_feet(h, batch, state_dev, inst_dev, nullptr, out_traj_dev + (size_t)t * batch, feet_dev, stream, t == 0 ? 1 : 2);
     return rc;
 }
 

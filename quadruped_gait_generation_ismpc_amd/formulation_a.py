@@ -38,7 +38,8 @@ EXPORTS_A = ["ismpc_a_params_default", "ismpc_a_gait_default", "ismpc_a_plan", "
              "ismpc_a_feet_rows", "ismpc_a_feet_init_device", "ismpc_a_tick_feet_batch_device",
              "ismpc_a_rollout_feet_device", "ismpc_a_foot_trajectories", "ismpc_a_write_trajectory_txt",
              "ismpc_a_add_plan", "ismpc_a_tick_batch_inst_device", "ismpc_a_rollout_inst_device", "ismpc_a_set_warm_history", "ismpc_a_reserve", "ismpc_a_set_precision",
-             "ismpc_a_last_deferred"]
+             "ismpc_a_last_deferred", "ismpc_a_feet_init_inst_device", "ismpc_a_tick_feet_batch_inst_device",
+             "ismpc_a_rollout_feet_inst_device"]
 HAVE_F32 = True        # the QP solve also exists in fp32 (GaitGenerator(..., precision="f32"))
 FEET_PAD = 8
 
@@ -72,6 +73,9 @@ def _l():
         lib.ismpc_a_reserve.argtypes = [vp, ci]; lib.ismpc_a_reserve.restype = ci
         lib.ismpc_a_set_precision.argtypes = [vp, ci]; lib.ismpc_a_set_precision.restype = ci
         lib.ismpc_a_last_deferred.argtypes = [vp]; lib.ismpc_a_last_deferred.restype = ci
+        lib.ismpc_a_feet_init_inst_device.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp]; lib.ismpc_a_feet_init_inst_device.restype = ci
+        lib.ismpc_a_tick_feet_batch_inst_device.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]; lib.ismpc_a_tick_feet_batch_inst_device.restype = ci
+        lib.ismpc_a_rollout_feet_inst_device.argtypes = [vp, ci, vp, vp, ci, vp, vp, vp]; lib.ismpc_a_rollout_feet_inst_device.restype = ci
         _bound = True
     return lib
 
@@ -207,6 +211,46 @@ class GaitGenerator:
         if n < 0:
             raise IsmpcAError(_l().ismpc_a_last_error().decode())
         return n
+
+    def feet_init_inst_torch(self, gaits, foot_plans, inst_u8):
+        """Per-instance gait parameters: one GaitA and one foot_plan per base plan of the handle (same row count); every
+        instance starts from the foot plan of its own base plan.  Returns float64 tensor [batch, rows + FEET_PAD, 8]."""
+        import torch
+        rows = max(np.asarray(f).shape[0] for f in foot_plans)           # the trot generator writes n_gait rows, the walk one n_gait + 1:
+        pad = lambda f: np.concatenate([f, np.repeat(f[-1:], rows - f.shape[0], 0)])   # a plan holds its last row beyond its end
+        fps = np.ascontiguousarray(np.stack([pad(np.asarray(f, dtype=np.float64)) for f in foot_plans]))
+        ga = (GaitA * len(gaits))(*gaits)
+        b = inst_u8.shape[0]
+        feet = torch.empty((b, fps.shape[1] + FEET_PAD, 8), dtype=torch.float64, device=inst_u8.device)
+        stream = torch.cuda.current_stream(inst_u8.device).cuda_stream
+        rc = _l().ismpc_a_feet_init_inst_device(self._h, C.cast(ga, C.c_void_p), fps.ctypes.data_as(C.c_void_p), fps.shape[1], len(gaits), b,
+                                                C.c_void_p(inst_u8.data_ptr()), C.c_void_p(feet.data_ptr()), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise IsmpcAError(_l().ismpc_a_last_error().decode())
+        return feet
+
+    def rollout_feet_inst_torch(self, state_u8, inst_u8, feet, ticks):
+        import torch
+        b = state_u8.shape[0]
+        traj = torch.empty((ticks, b, 80), dtype=torch.uint8, device=state_u8.device)
+        stream = torch.cuda.current_stream(state_u8.device).cuda_stream
+        rc = _l().ismpc_a_rollout_feet_inst_device(self._h, b, C.c_void_p(state_u8.data_ptr()), C.c_void_p(inst_u8.data_ptr()), int(ticks),
+                                                   C.c_void_p(traj.data_ptr()), C.c_void_p(feet.data_ptr()), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise IsmpcAError(_l().ismpc_a_last_error().decode())
+        return traj
+
+    def tick_feet_inst_torch(self, state_u8, inst_u8, feet, push=None):
+        import torch
+        b = state_u8.shape[0]
+        out = torch.empty((b, 80), dtype=torch.uint8, device=state_u8.device)
+        stream = torch.cuda.current_stream(state_u8.device).cuda_stream
+        rc = _l().ismpc_a_tick_feet_batch_inst_device(self._h, b, C.c_void_p(state_u8.data_ptr()), C.c_void_p(inst_u8.data_ptr()),
+                                                      C.c_void_p(push.data_ptr()) if push is not None else None, C.c_void_p(out.data_ptr()),
+                                                      C.c_void_p(feet.data_ptr()), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise IsmpcAError(_l().ismpc_a_last_error().decode())
+        return out
 
     def set_warm_history(self, enabled=True):
         """Caller-driven tick loops: start every QP from the working set the same instance had in the previous call."""

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Where the PCIe-inclusive host entry point (ismpc_solve_batch) spends its time: pageable against page-locked caller buffers,
+staged (DMA in -> kernel -> DMA out) against zero copy on either side (ISMPC_HOST_MODE).  GPU box.
+usage: python scripts/host_path_probe.py [batch]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import quadruped_gait_generation_ismpc_amd as q
+from quadruped_gait_generation_ismpc_amd import workload
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+tin = workload.make_batch(100, B)
+p = q.default_params(N=100)
+print("ISMPC_HOST_ALLOC_FLAGS =", os.environ.get("ISMPC_HOST_ALLOC_FLAGS", "default"))
+pin_in, pin_out = q.PinnedRecords(B, q.TICK_IN), q.PinnedRecords(B, q.TICK_OUT)
+pin_in.array[:] = tin
+pag_out = np.zeros(B, dtype=q.TICK_OUT)
+
+
+def rate(s, a, o, reps=40):
+    s.solve_batch(a, out=o); s.solve_batch(a, out=o)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); s.solve_batch(a, out=o); ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return 1e3 * ts[len(ts) // 2], 1e3 * ts[0]
+
+
+for chunks in ("1", "zc_in", "zc_out", "zc_both"):
+    os.environ["ISMPC_HOST_MODE"] = {"1": "0", "zc_in": "1", "zc_out": "2", "zc_both": "3"}[chunks]
+    s = q.MPCSolver(q.reference_plan(params=p), params=p)
+    med, mn = rate(s, pin_in.array, pin_out.array)
+    print(f"pinned   mode={chunks:>7}: median {med:.3f} ms  min {mn:.3f} ms  -> {B / med * 1e3:.3e} ticks/s", flush=True)
+    if chunks == "1":
+        med, mn = rate(s, tin, pag_out)
+        print(f"pageable serial   : median {med:.3f} ms  min {mn:.3f} ms  -> {B / med * 1e3:.3e} ticks/s", flush=True)
+        ref = pag_out.copy()
+    assert pin_out.array.tobytes() == ref.tobytes()
+    s.close()

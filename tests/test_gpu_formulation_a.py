@@ -302,6 +302,55 @@ def test_per_instance_parameters_against_oracle(FA, backend):
         assert np.abs(o2["f0"][i] - r["f0"]).max() <= 1e-7, i
 
 
+def test_per_instance_swing_foot_qps_against_oracle(FA, tmp_path):
+    """SURVEY 8f2 for Monte-Carlo batches (BASELINE configs[4]): every instance carries its own gait (trot / walk by base plan),
+    CoM height, step timing and footstep count, and its own foot plan re-placed by the swing-foot QP after every tick
+    (trotting/quad_as_bip_no_plots.m:332-426 + compute_two_feet1.m, walking/quad_walk_no_plots.m:336-504 +
+    compute_one_feet_walk.m:84-140).  One device rollout against one oracle run with enable_feet() per instance: foot plans,
+    and the four foot files wherever the script's writer applies (the trot writer hard-codes 50 swing rows per step)."""
+    import torch
+    from oracle import oracle_a as A
+    Cn, Pn, n, ticks = 200, 400, 8, 420
+    phi, dA = np.pi / 4, 0.1
+    inst = _mc_instances(FA, A, n, seed=9)
+    gaits = [FA.default_gait(k, phi, dA) for k in (A.TROT, A.WALK)]
+    fplans, plans = zip(*[FA.plan(g) for g in gaits])
+    gen = FA.GaitGenerator(FA.default_params(A.TROT, C=Cn, P=Pn, F=6), plans[0]); gen.add_plan(plans[1])
+    d_inst = q_to_dev(inst)
+    st = q_to_dev(gen.initial_state(0.88, batch=n))
+    feet = gen.feet_init_inst_torch(gaits, fplans, d_inst)
+    out = q_from_dev(gen.rollout_feet_inst_torch(st, d_inst, feet, ticks), FA.OUT_A)
+    torch.cuda.synchronize()
+    assert (out["status"] == 0).all()
+    fpl = feet.cpu().numpy()
+    moved = 0
+    for i in range(n):
+        kind = A.TROT if inst["plan"][i] == 0 else A.WALK
+        p = A.params(kind, C_=Cn, P=Pn, F=int(inst["F"][i]), step=int(inst["step"][i]), ds=int(inst["ds"][i]), Qf=float(inst["Qf"][i]))
+        p.height = float(inst["height"][i])
+        sim = A.SimA(A.gait(kind, phi, dA), p, backend="gi")
+        sim.enable_feet()
+        ref = sim.run(ticks)
+        assert (ref["rv"] == 0).all()
+        assert np.abs(out["com_before"][:, i] - ref["com_before"]).max() <= 1e-6
+        fo = sim.foot_plan()
+        assert np.abs(fpl[i][:fo.shape[0]] - fo).max() <= 1e-7, (i, np.abs(fpl[i][:fo.shape[0]] - fo).max())
+        moved += int(np.abs(fo[:len(fplans[inst["plan"][i]])] - fplans[inst["plan"][i]][:fo.shape[0]]).max() > 1e-9)
+        step = int(inst["step"][i])
+        if kind == A.WALK or step > 50:
+            files = FA.foot_trajectories(gaits[inst["plan"][i]], step, fpl[i], ticks)
+            assert np.abs(files - sim.foot_trajectories(ticks)).max() <= 1e-7, i
+            if i < 2:
+                pth = tmp_path / f"foot_fl_{i}.txt"
+                FA.write_trajectory_txt(str(pth), files[0])
+                assert np.abs(np.loadtxt(pth) - files[0]).max() <= 1e-6
+    assert moved >= n // 2                                     # the QPs did re-place feet
+    # handle-wide entry points still refuse a per-instance batch that was never initialised
+    gen2 = FA.GaitGenerator(FA.default_params(A.TROT, C=Cn, P=Pn, F=6), plans[0]); gen2.add_plan(plans[1])
+    with pytest.raises(FA.IsmpcAError):
+        gen2.rollout_feet_inst_torch(q_to_dev(gen2.initial_state(0.88, batch=n)), d_inst, feet, 1)
+
+
 def test_per_instance_invalid_records_are_flagged(FA):
     import torch
     from oracle import oracle_a as A
