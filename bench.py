@@ -38,12 +38,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# VALU peaks the executed flops are priced against: 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz = 78.6 TFLOP/s for
-# v_fma_f64 AND for the unpacked v_fma_f32 the fp32 solve issues (the library is built -fno-slp-vectorize: no v_pk_fma_f32,
-# which is what the 157.3 TFLOP/s FP32 spec figure assumes).  profiles/r03/valu_peak.json holds the rates measured on the box.
-PEAK_TFLOPS = {"f64": 78.6, "f32": 78.6}
-PEAK_NOTE = ("78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz: the FP64 vector (= matrix) peak, and the peak of UNPACKED fp32 FMAs "
-             "(the fp32 kernels issue no v_pk_*; the 157.3 TFLOP/s spec figure needs packed fp32).  Measured rates: profiles/r03/valu_peak.json")
+# VALU peaks the executed flops are priced against (MI355X_MICROARCH.md / AMD spec): FP64 vector = matrix 78.6 TFLOP/s (1024 SIMDs x
+# 16 lanes x 2 flop x 2.4 GHz: one wave64 v_fma_f64 per 4 cycles), FP32 vector 157.3 TFLOP/s (one wave64 v_fma_f32 per 2 cycles).
+# Measured on the box with scripts/micro/valu_peak.hip (profiles/r03/valu_peak.json): v_fma_f64 69.3, UNPACKED v_fma_f32 123.1,
+# v_pk_fma_f32 146.0 TFLOP/s -- the fp32 solve issues unpacked instructions (the library is built -fno-slp-vectorize) and they do run
+# at the two-cycle rate.  A kernel that executes both types is priced against the blend: peak = flops / (f64/78.6 + f32/157.3).
+PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}
+PEAK_NOTE = ("FP64 vector (= matrix) 78.6 TFLOP/s, FP32 vector 157.3 TFLOP/s; a kernel executing both is priced against the blend flops / (f64 / 78.6 + "
+             "f32 / 157.3).  Measured FMA rates on the box (profiles/r03/valu_peak.json): v_fma_f64 69.3, unpacked v_fma_f32 123.1, v_pk_fma_f32 146.0 TFLOP/s")
 CLOCK_GHZ = 2.4              # MI355X_MICROARCH.md "Max clock"
 SIMDS = 256 * 4
 PROFILES = os.path.join(ROOT, "profiles", "r03")
@@ -343,9 +345,10 @@ def roofline(leg, kernel, kernel_ms, batch, dtype, alg_flops, alg_bytes, extra=N
     per_step = float(j.get("launches_per_step", 1))
     fl64, fl32 = d.get("flops_f64_per_launch"), d.get("flops_f32_per_launch")
     ex = {"source": f"profiles/r03/pmc_{leg}.json"}
-    if fl64 is not None and fl32 is not None:
+    if fl64 is not None and fl32 is not None and fl64 + fl32 > 0:
         flops = (fl64 + fl32) * per_step
         rf["achieved"] = flops / (kernel_ms * 1e-3) / 1e12
+        rf["peak"] = peak = (fl64 + fl32) / (fl64 / PEAK_TFLOPS["f64"] + fl32 / PEAK_TFLOPS["f32"])      # blend by executed type
         rf["frac"] = rf["achieved"] / peak
         ex.update({"flops_f64_per_launch": fl64 * per_step, "flops_f32_per_launch": fl32 * per_step,
                    "fp_wave_instructions_per_launch": (d.get("fp_insts_f64_per_launch", 0.0) + d.get("fp_insts_f32_per_launch", 0.0)) * per_step,
@@ -353,8 +356,12 @@ def roofline(leg, kernel, kernel_ms, batch, dtype, alg_flops, alg_bytes, extra=N
     if "SQ_INSTS_VALU" in c:
         valu = c["SQ_INSTS_VALU"] * per_step
         issue_ms = valu * 4.0 / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
-        ex.update({"valu_insts_per_launch": valu, "valu_issue_ms": issue_ms, "valu_issue_frac": issue_ms / kernel_ms,
+        ex.update({"valu_insts_per_launch": valu, "valu_issue_ms": issue_ms, "valu_issue_frac": min(1.0, issue_ms / kernel_ms),
+                   "valu_issue_note": "VALU wave-instructions x 4 cycles / 1024 SIMDs / 2.4 GHz over kernel_ms: an upper estimate (32-bit instructions can issue every 2 cycles, and the chip clocks below 2.4 GHz under load)",
                    "mfma_f64_mops_per_launch": c.get("SQ_INSTS_VALU_MFMA_MOPS_F64")})
+        if "SQ_ACTIVE_INST_VALU" in c and c.get("SQ_BUSY_CYCLES"):
+            # counters only (same pass, clock-independent): VALU-active quad-cycles x 4 per SIMD over the busy cycles of a shader engine (32 of them)
+            ex["valu_busy_frac"] = min(1.0, c["SQ_ACTIVE_INST_VALU"] * 4.0 / SIMDS / (c["SQ_BUSY_CYCLES"] / 32.0))
     rf["executed"] = ex
     hbm = d.get("hbm_bytes_per_launch")
     rf["traffic"] = hbm * per_step if hbm is not None else None

@@ -37,6 +37,21 @@
 
 namespace ismpc_a {
 
+// -DISMPC_A_PHASES (diagnostic build, scripts/phases_a.py): shader-clock time of every wavefront, split by solver phase and summed
+// over the launch (s_memtime deltas, wave-uniform accumulators, one atomicAdd per phase per QP).  Nothing of it exists in the product build.
+#ifdef ISMPC_A_PHASES
+constexpr int NPH = 16;
+static __device__ unsigned long long g_phase[NPH];
+#define PH_DECL unsigned long long ph_t_ = __builtin_amdgcn_s_memtime(); unsigned ph_acc_[NPH]; for (int k_ = 0; k_ < NPH; ++k_) ph_acc_[k_] = 0u
+// the time since the previous mark belongs to phase k_ (a compile-time constant: the accumulators stay in scalar registers)
+#define PH(k_) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc_[k_] += (unsigned)(t_ - ph_t_); ph_t_ = t_; } while (0)
+#define PH_FLUSH() do { if (lane == 0) { _Pragma("unroll") for (int k_ = 0; k_ < NPH; ++k_) if (ph_acc_[k_]) atomicAdd(&g_phase[k_], (unsigned long long)ph_acc_[k_]); } _Pragma("unroll") for (int k_ = 0; k_ < NPH; ++k_) ph_acc_[k_] = 0u; } while (0)
+#else
+#define PH_DECL do {} while (0)
+#define PH(k_) do {} while (0)
+#define PH_FLUSH() do {} while (0)
+#endif
+
 // ---- precision traits ---------------------------------------------------------------------------------------------------
 template <typename R> struct Num;
 template <> struct Num<double> {
@@ -340,8 +355,10 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     const int share = (int)(((long long)total_qp * static_q) / (16ll * nwaves));
     int st_cur = gwave * share;
     const int st_end = st_cur + share, dyn_base = nwaves * share;
+    PH_DECL;
     for (;;) {
         LANE_FRESH();
+        PH(0);                                             // 0: between QPs
         int work;
         if (st_cur < st_end) work = st_cur++;
         else {
@@ -489,6 +506,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         int dg_ns = 0, dg_cold = 0, dg_q0 = 0, dg_part = 0, dg_why = 0;   // diagnostic build (scripts/iters_hist.py): see the packing at the output
 #endif
         R muE = R(0);
+        PH(1);                                             // 1: record, gait parameters, per-row set-up, tail
         bool done_opt = false;                                // the block passes ended on a checked optimum: nothing left to do
         if (status == 0) {
             // ---- equality first: u = (b / a'a) a
@@ -511,6 +529,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 const R bs = wave_scan_up(lc) - lc;
 #pragma unroll
                 for (int k = 0; k < RL; ++k) vv[k] = dt * (vv[k] + bs) - (w1[k] * L.fl[K1_(k)] + (R(1) - w1[k]) * L.fl[K1_(k) + 1]);
+                PH(2);                                     // 2: row values
             };
 
             // D = a'a - G_EE >= 0, the (stability, stability) entry of the small system with its sign flipped.  Both terms are sums
@@ -585,6 +604,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 const R cc_e = (lane < m) ? Tr[m] * frcp(dg) : R(0);             // lane e: cc[e]
                 if (lane < m) L.cc[lane] = cc_e;
                 WAVE_LDS_SYNC();
+                PH(3);                                     // 3: small system (Gauss-Jordan)
                 return cc_e;
             };
 
@@ -592,6 +612,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             // minimiser u, f and all multipliers; leaves G(W) in L.G and prv / nxt of every row
             auto block_solve = [&](const unsigned long long kmask) __attribute__((always_inline)) {
                 LANE_FRESH();
+                PH(10);                                    // 10: block passes: selection (what ran since the row values)
                 // ---- previous / next active row of every row (active or not): exclusive max scan, exclusive suffix min scan
                 int nact = 0;
                 R cvr[RL];
@@ -621,6 +642,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     for (int k = RL - 1; k >= 0; --k) { const int i = lane * RL + k + 1; SET_NXT_(k, run); if (i <= C && STA_(k) != 0) run = i; }
                 }
                 WAVE_LDS_SYNC();
+                PH(4);                                     // 4: block solve: links (prev / next scans)
                 // ---- G = V'K^-1 V / dt^2 and g = V'K^-1 c / dt^2 as sums over consecutive active pairs (p, i) of
                 // d d' / gap, d = V_i - V_p.  V_i = Phi(theta_i) + dt PA_i e_E with theta_i the row's mapping weights over the
                 // F footstep columns and Phi a fixed sparse map, so everything follows from the Gram sums of
@@ -666,9 +688,11 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                                 acc[NT + 2 * F] += om * dE * dE; acc[NT + 2 * F + 1] += om * dE * dc;
                             }
                         }
+                        PH(5);                             // 5: block solve: Gram accumulation
                         wave_fold_sums<R, NS>(acc, L.th, lane);
                     }
                     WAVE_LDS_SYNC();
+                    PH(6);                                 // 6: block solve: fold over the wavefront
                     // Phi(e): e < F -> +col e+1 ; e > F -> -col (e-F) + col (e-F-1) [if >= 1] ; all scaled by 1/sqrt(Qf)
                     auto TH = [&](int r, int q) -> R {                       // Theta(r, q), 1-based, symmetric
                         const int lo_ = min(r, q), hi_ = max(r, q);
@@ -710,7 +734,9 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 }
                 WAVE_LDS_SYNC();
                 qz = nact;
+                PH(7);                                     // 7: block solve: G and right-hand side from the sums
                 Dd = stability_defect(); Dee = (R)Dd;
+                PH(8);                                     // 8: block solve: stability defect
                 (void)solve_small(kmask);
                 const R cEw = L.cc[F];
                 // comb[r] = (cc[r-1] - ck[r] + ck[r+1]) / sqrt(Qf), r = 1..F: what a row sees through its two footstep columns
@@ -761,6 +787,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 if (klane) fr = L.pf[lane] - L.comb[lane];
                 muE = cEw;
                 WAVE_LDS_SYNC();
+                PH(9);                                     // 9: block solve: slopes, multipliers, u
             };
 
             // ================= block warm start (primal-dual active-set passes) =================
@@ -973,6 +1000,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #ifdef ISMPC_A_DIAG
                 dg_ns += nsolve; dg_cold = cold ? dg_why : 0; dg_q0 = cold ? 0 : qz;
 #endif
+                PH(10);
                 pass_solves = nsolve; pass_cold = cold;
                 if (defer_qp) break;
                 if (cold) {
@@ -1022,6 +1050,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     }
                 }
                 const R vmin = wave_min(cand);
+                PH(11);                                    // 11: Goldfarb-Idnani: search for the most violated row
                 if (!(vmin < R(0))) { gi_leave = true; break; }                   // feasible: done
                 const int wl = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(cand == vmin));
                 const int cd = rl(code, wl);
@@ -1086,6 +1115,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     WAVE_LDS_SYNC();
                     const unsigned long long kmask = __builtin_amdgcn_ballot_w64(klane && kact != 0);   // bit r: Khat_r active
                     Dee = (R)Dd;
+                    PH(12);                                // 12: Goldfarb-Idnani: one step (new row, neighbours, right-hand side ...)
                     const R cc_e = solve_small(kmask);
                     const R cE = L.cc[F];
                     // ---- y = coefficients on the V columns (delta_Z - V cc = sg dt^2 k_i + V y); rows see the footstep
@@ -1263,6 +1293,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         --qk;
                     }
                 }
+                PH(12);                                    // ... (step lengths, primal / dual update, row enters / leaves)
                 if (failed) { gi_leave = true; break; }
                 ++gi_adds;
             }
@@ -1274,6 +1305,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             // without any inactive row showing it.  One block solve of the final working set (kinematic rows included)
             // polishes such a point; if it still fails, the QP is reported infeasible (the reference's quadprog returns no
             // solution on infeasible QPs).
+            PH(15);
             if (status == 0 && !done_opt && !defer_qp) {
                 auto off_point = [&]() __attribute__((always_inline)) -> bool {
                     LANE_FRESH();
@@ -1317,6 +1349,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             }
         }
 
+        PH(13);                                            // 13: final check / polish
         if (defer_qp) {                                       // nothing of this QP is written here: the fp64 re-solve owns it
             if (lane == 0) defer_list[atomicAdd(defer_count, 1)] = qp;
             WAVE_LDS_SYNC();
@@ -1373,6 +1406,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             }
         }
         WAVE_LDS_SYNC();
+        PH(14);                                            // 14: history, LIP update, outputs
+        PH_FLUSH();
 #undef K1_
 #undef STA_
 #undef SET_STA_

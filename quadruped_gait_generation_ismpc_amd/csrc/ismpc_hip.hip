@@ -32,6 +32,7 @@
 #include <new>
 #include <algorithm>
 #include "ismpc_tables.hpp"
+#include "ismpc_sweep.hpp"
 
 // Floating-point contraction is OFF for this file: every fused multiply-add is written as fma().  The same tick arithmetic
 // is inlined into several kernels (per-tick, one-launch, in-kernel rollout, resume) whose results must agree bit for bit,
@@ -55,6 +56,8 @@ struct DevConst {
     int flat;
     // inequality fallback (0 <= S u <= 1e4 active)
     const double *HSt, *SHSt;
+    const DevConst* sets; int nsets;  // parameter sweeps (ismpc_create_sweep): one record per parameter set, its own tables and scalars; the
+                                      // instance's record names its set (ismpc_tick_in.reserved).  NULL / 0 for a plain handle
     int* zflag;                       // id of the last launch that deferred an instance to the fallback kernel
     double* zpool; int* zbusy;        // active-set fallback: slots of zstride doubles (G^-1 cap x cap + per-entry vectors), one lock word per slot
     int zslots, zcap; size_t zstride;
@@ -1230,7 +1233,7 @@ __device__ __forceinline__ unsigned long long stamp_now()
 
 // What one instance carries from tick to tick (group-uniform: every lane of the group holds the same values) and what a tick
 // produces (valid in lane 0 of the group).
-struct QState { double x, y, z, xd, yd, zd; Walk w; };
+struct QState { double x, y, z, xd, yd, zd; Walk w; int ps; };     // ps: parameter set of the instance (sweep handles; -1 = invalid record)
 struct QOut { double x, y, z, xd, yd, zd, uz0, ux0, uy0; int status, itx, ity; };
 
 // One tick of one instance per lane group, registers in, registers out.  `s.w` is the WalkState the tick runs with (caller
@@ -1257,7 +1260,10 @@ template <int R, int LPI> constexpr int wave_lds_double2() { return (64 / LPI) *
 #ifndef ISMPC_KF_ROLLOUT
 #define ISMPC_KF_ROLLOUT 0
 #endif
-template <int R, int LPI, int KF>
+// SW: parameter sweep -- the groups of a wavefront may belong to different parameter sets: what depends on the set (tables
+// of the vertical stage, tails, mass, eta, box widths, bounds on S u) is read through the instance's own record c.sets[s.ps]
+// (per-lane loads); horizon, plan, dt, g and the gate are the handle's.  SW = false compiles to exactly the plain kernel.
+template <int R, int LPI, int KF, bool SW = false>
 __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lane, const QState& s, QOut& o, double* __restrict__ u_traj_inst,
                                                 double2* __restrict__ lds_wave)
 {
@@ -1267,8 +1273,15 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
     const double dt = c.dt;
     const Walk& w = s.w;
     const double x0 = s.x, y0 = s.y, z0 = s.z, xd0 = s.xd, yd0 = s.yd, zd0 = s.zd;
+    const DevConst* P = SW ? c.sets + (s.ps >= 0 ? s.ps : 0) : nullptr;
+    const double* p_vqT = SW ? P->vqT : c.vqT;
+    const double p_z_lo = SW ? P->z_lo : c.z_lo, p_z_hi = SW ? P->z_hi : c.z_hi;
+    const double p_inv_mass = SW ? P->inv_mass : c.inv_mass, p_inv_eta = SW ? P->inv_eta : c.inv_eta;
+    const double p_half_run = SW ? P->half_run : c.half_run, p_half_first = SW ? P->half_first : c.half_first;
+    const double* p_tailx = SW ? P->tailx : c.tailx; const double* p_taily = SW ? P->taily : c.taily;
+    const double p_dt_over_mass = SW ? P->dt_over_mass : c.dt_over_mass, p_h_des = SW ? P->h_des : c.h_des;
     int idx;
-    const int gate_status = gate_tick(c, w, idx);     // group-uniform; a gated group runs the arithmetic on idx = 0 and drops it
+    const int gate_status = gate_tick(c, w, idx) | ((SW && s.ps < 0) ? ISMPC_ST_BAD_INDEX : 0);     // group-uniform; a gated group runs the arithmetic on idx = 0 and drops it
     int status = gate_status;
     const bool run = gate_status == 0;
     if (!run) idx = 0;
@@ -1278,7 +1291,7 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
 
     // ---- vertical stage from the affine tables (MPCSolver.cpp:223-243, is_running :262-263)
     const int pat = (run && w.fc > 1 && w.mpc < c.npat) ? w.mpc : c.npat;
-    const double2* T = reinterpret_cast<const double2*>(c.vqT) + (size_t)pat * (R * 3 * LPI) + li;  // 3 x 16 bytes per sample, lane-contiguous
+    const double2* T = reinterpret_cast<const double2*>(p_vqT) + (size_t)pat * (R * 3 * LPI) + li;  // 3 x 16 bytes per sample, lane-contiguous
     // midpoint window [idx, idx + LPI R) of this instance -> LDS, coalesced (consumed after the scan; MPCSolver.cpp:328-338,388-389)
     constexpr int MIDM = midm<R>();
     double2* Lm = lds_wave + (lane / LPI) * (LPI * MIDM);
@@ -1325,7 +1338,7 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
             if (n < N) { smin = fmin(smin, su[r]); smax = fmax(smax, su[r]); }
         }
     }
-    const double zlo_t = c.z_lo - 1e-11 * fmax(1.0, fabs(c.z_lo)), zhi_t = c.z_hi + 1e-11 * fmax(1.0, fabs(c.z_hi));
+    const double zlo_t = p_z_lo - 1e-11 * fmax(1.0, fabs(p_z_lo)), zhi_t = p_z_hi + 1e-11 * fmax(1.0, fabs(p_z_hi));
     const bool viol = smin < zlo_t || smax > zhi_t;                                                // MPCSolver.cpp:158-160, beyond rounding
     const unsigned long long vmask = __builtin_amdgcn_ballot_w64(viol);
     const bool deferred = run && (((vmask >> (lane & (64 - LPI))) & ((1ull << LPI) - 1ull)) != 0ull);
@@ -1340,7 +1353,7 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
         for (int r = 0; r < R; ++r) {
             const double2 tq = reinterpret_cast<const double2*>(c.tzgT)[r * LPI + li];
             const double zpos = su[r] + fma(tq.x, zd0, z0) + tq.y;                  // S u + T_bar_z s + T_bar_g_z
-            const double zacc = fma(c.inv_mass, u[r], -c.g);
+            const double zacc = fma(p_inv_mass, u[r], -c.g);
             const double lam = (c.g + zacc) * frcp(zpos);
             if (r == 0) lam0_l = lam;
             le_[r] = (lam < c.gate) ? 0.0 : lam;
@@ -1387,7 +1400,7 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
     STAMP(2);                                         // tables arrived, lambda / A_j / local products done
     grp_scan_step<LPI, 0>(Y, li); grp_scan_step<LPI, 1>(Y, li); grp_scan_step<LPI, 2>(Y, li); grp_scan_step<LPI, 3>(Y, li);
     grp_scan_step<LPI, 4>(Y, li);
-    const double ie = c.inv_eta;
+    const double ie = p_inv_eta;
     const double cva = fma(ie, Y.c, Y.a), cvb = fma(ie, Y.d, Y.b);       // C_sc (suffix product from this lane's first sample)
     double c0 = Grp<LPI>::next_or(1.0, cva, li), c1 = Grp<LPI>::next_or(ie, cvb, li);                 // the lane needs it one lane up
     // ---- Aeq(n) = C_sc phi_input(:,n) = c_n B_n, walking the lane's samples backwards
@@ -1398,7 +1411,7 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
         const double k0 = fma(c0, ch1[r], fma(c1, s2[r], c0)), k1 = fma(c1, ch1[r], fma(c0, s1[r], c1));
         c0 = k0; c1 = k1;
     }
-    const double h = (w.fc > 1) ? c.half_run : c.half_first;                                          // MPCSolver.cpp:328-338
+    const double h = (w.fc > 1) ? p_half_run : p_half_first;                                          // MPCSolver.cpp:328-338
     double q0 = 0.0, s_ax = 0.0, s_ay = 0.0, mx0 = 0.0, my0 = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();          // the staged window is complete
 #pragma unroll
@@ -1411,8 +1424,8 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
     }
     q0 = Grp<LPI>::sum(q0); s_ax = Grp<LPI>::sum(s_ax); s_ay = Grp<LPI>::sum(s_ay);
     // C_sc phi_state sits in lane 0 of the group (cva, cvb there); beq - a'mid (MPCSolver.cpp:381-384), group-uniform
-    const double bpx = Grp<LPI>::bcast0((c.tailx[idx] - fma(cva, x0, cvb * xd0)) - s_ax);
-    const double bpy = Grp<LPI>::bcast0((c.taily[idx] - fma(cva, y0, cvb * yd0)) - s_ay);
+    const double bpx = Grp<LPI>::bcast0((p_tailx[idx] - fma(cva, x0, cvb * xd0)) - s_ax);
+    const double bpy = Grp<LPI>::bcast0((p_taily[idx] - fma(cva, y0, cvb * yd0)) - s_ay);
     const double sgx = (bpx < 0.0) ? -1.0 : 1.0, sgy = (bpy < 0.0) ? -1.0 : 1.0;
     STAMP(3);                                         // scan, backward walk, midpoints, reductions done
     // min 1/2|v|^2, a'v = bp, |v| <= h  ->  v_n = sg sign(a_n) min(tau |a_n|, h): Newton on the concave piecewise-linear
@@ -1503,8 +1516,8 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
     if (li == 0 && run) {
         o.uz0 = u[0];
         o.z = fma(dt, zd0, z0);
-        o.zd = fma(c.dt_over_mass, o.uz0, zd0) - dt * c.g;
-        if (isnan(o.z)) { o.z = c.h_des; status |= ISMPC_ST_Z_NAN; }
+        o.zd = fma(p_dt_over_mass, o.uz0, zd0) - dt * c.g;
+        if (isnan(o.z)) { o.z = p_h_des; status |= ISMPC_ST_Z_NAN; }
         if (isnan(o.zd)) { o.zd = 0.0; status |= ISMPC_ST_Z_NAN; }
         const double A0a = 1.0 + ch1[0], A0b = s1[0], A0c = s2[0];
         if (lam0_l > c.gate) {                                            // MPCSolver.cpp:322
@@ -1558,7 +1571,7 @@ __device__ __forceinline__ void store_feedback(const DevConst& c, ismpc_tick_in*
 }
 
 // One launch = one tick: record in, record out (and, in the host-driven closed loop, state fed back in place)
-template <int R, int LPI, int KF>
+template <int R, int LPI, int KF, bool SW = false>
 __device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_raw, const int batch, const int lane,
                                                 const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                                                 ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
@@ -1573,8 +1586,10 @@ __device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_
     s.w = load_walk(c, rec, rollout_frame);
     s.x = rec->com_pos[0]; s.y = rec->com_pos[1]; s.z = rec->com_pos[2];
     s.xd = rec->com_vel[0]; s.yd = rec->com_vel[1]; s.zd = rec->com_vel[2];
+    s.ps = 0;
+    if (SW) { const int ps = rec->reserved; s.ps = (ps >= 0 && ps < c.nsets) ? ps : -1; }       // an unknown set: ISMPC_ST_BAD_INDEX, state passed through
     QOut o;
-    const bool deferred = tick_group_core<R, LPI, KF>(c, lane, s, o, (u_traj && valid) ? u_traj + (size_t)gi * 3 * c.N : nullptr, lds_wave);
+    const bool deferred = tick_group_core<R, LPI, KF, SW>(c, lane, s, o, (u_traj && valid) ? u_traj + (size_t)gi * 3 * c.N : nullptr, lds_wave);
     if ((lane & (LPI - 1)) == 0 && valid) {
         if (out) store_record(out + gi, o);
         if (zmark) zmark[gi] = deferred ? 1 : 0;
@@ -1588,7 +1603,7 @@ __device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_
 #ifndef ISMPC_QUAD_WAVES
 #define ISMPC_QUAD_WAVES 4
 #endif
-template <int R, int LPI>
+template <int R, int LPI, bool SW = false>
 __global__ __launch_bounds__(64 * ISMPC_QUAD_WAVES)
 void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                      ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
@@ -1600,7 +1615,7 @@ void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, 
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
     if (wave * IPW >= batch) return;
-    tick_group_body<R, LPI, ISMPC_KF_MAIN>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
+    tick_group_body<R, LPI, ISMPC_KF_MAIN, SW>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
 }
 
 // Latency variant for small batches (every wavefront resident at once): a wavefront that deferred one of its
@@ -1657,7 +1672,7 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
         QState s;
         s.w.sim = rec->simulation_time; s.w.mpc = rec->mpc_iter; s.w.ctl = rec->control_iter; s.w.fc = rec->footstep_counter;
         s.x = rec->com_pos[0]; s.y = rec->com_pos[1]; s.z = rec->com_pos[2];
-        s.xd = rec->com_vel[0]; s.yd = rec->com_vel[1]; s.zd = rec->com_vel[2];
+        s.xd = rec->com_vel[0]; s.yd = rec->com_vel[1]; s.zd = rec->com_vel[2]; s.ps = 0;
         bool alive = true;                                              // FB = false: false once the instance is parked
         int stopped = -1;
         for (int t = t0; t < ticks; ++t) {
@@ -1711,7 +1726,7 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
 }
 
 // Second launch of every tick of a large batch: exits at once unless the first one deferred instances (active inequality rows).
-template <int R>
+template <int R, bool SW = false>
 __global__ __launch_bounds__(256)
 void ismpc_tick_affine_fallback(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                                 ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
@@ -1721,7 +1736,13 @@ void ismpc_tick_affine_fallback(const DevConst c, const ismpc_tick_in* __restric
     const int lane = threadIdx.x & 63;
     const int wave0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int gi = wave0; gi < batch; gi += gridDim.x * 4)
-        if (zmark[gi]) tick_affine_body<R, true>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+        if (zmark[gi]) {
+            if (SW) {
+                // one instance per wavefront: its parameter set is wave-uniform, the body runs on that set's own record
+                const int ps = __builtin_amdgcn_readfirstlane((((rollout_frame >= 0) ? state_rw : in_ro) + gi)->reserved);
+                tick_affine_body<R, true>(c.sets[ps], gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);    // (a deferred instance has a valid set)
+            } else tick_affine_body<R, true>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+        }
 }
 
 // ------------------------------------------------------------------------
@@ -1767,6 +1788,8 @@ struct ismpc_handle {
                               // there, slower from 3 072 on), 16 otherwise; the tables exist in both layouts
     const double* vqT32 = nullptr; const double* tzgT32 = nullptr;
     bool kernel_rollout = true;   // closed loops run inside one launch (ismpc_rollout_quad); ISMPC_ROLLOUT=host: one launch per tick
+    bool sweep = false;           // ismpc_create_sweep: K parameter sets, tables built on the device (csrc/ismpc_sweep.hip)
+    ismpc::SweepSlabs sw; std::vector<ismpc_params> sets;
     hipStream_t last_stream = nullptr; bool used = false;   // stream of the previous launch: zmark / zstop outlive a call and are re-allocated
                                                             // only after that stream has drained (grow_sync)
 };
@@ -1844,6 +1867,18 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
             if (small) { cq.vqT = h->vqT32; cq.tzgT = h->tzgT32; }
             const int waves = (batch * lpi + 63) / 64;
             const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
+            if (h->sweep) {
+                // parameter sweep: the per-tick kernel reads each instance's set through c.sets (16 lanes per instance), two-launch form
+#define ISMPC_QUADS(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad<RR, 16, true>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid)
+                if (RQ == 4) ISMPC_QUADS(4, 16, 1); else if (RQ == 7) ISMPC_QUADS(7, 16, 2); else ISMPC_QUADS(8, 16, 2);
+#undef ISMPC_QUADS
+                if (zm) {
+                    if (R == 1) hipLaunchKernelGGL((ismpc_tick_affine_fallback<1, true>), fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid);
+                    else        hipLaunchKernelGGL((ismpc_tick_affine_fallback<2, true>), fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid);
+                }
+                HIP_TRY(hipGetLastError());
+                return ISMPC_OK;
+            }
             // every wavefront resident at once (<= 2 per SIMD) and a fallback to run: one launch that handles deferred instances itself
             if (zm && h->cus > 0 && waves <= 8 * h->cus) {
 #define ISMPC_QUADI(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad_inline<RR, LL, RW_>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid)
@@ -1920,10 +1955,20 @@ void ismpc_params_default(ismpc_params* p)
     p->lambda_gate = 2.0;                                   // MPCSolver.cpp:322
 }
 
-int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int device, ismpc_handle** out)
+static int create_impl(const ismpc_params* params, int K, bool sweep, const double* ftsp, int rows, int device, ismpc_handle** out)
 {
     if (!params || !ftsp || !out) return fail(ISMPC_E_INVALID, "null argument");
     *out = nullptr;
+    if (sweep) {
+        // the sets of a sweep share what fixes the shape of the problem; everything else may differ from set to set
+        if (K < 1 || K > 65535) return fail(ISMPC_E_INVALID, "a sweep holds 1 .. 65535 parameter sets");
+        for (int k = 0; k < K; ++k) {
+            const ismpc_params& a = params[0]; const ismpc_params& b = params[k];
+            if (a.N != b.N || a.S != b.S || a.F != b.F || a.M != b.M || a.mpc_dt != b.mpc_dt || a.control_dt != b.control_dt || a.g != b.g || a.lambda_gate != b.lambda_gate)
+                return fail(ISMPC_E_INVALID, "the parameter sets of a sweep share N, S, F, M, mpc_dt, control_dt, g and lambda_gate");
+            if (!(b.mass > 0) || !(b.h_des > 0) || !(b.q_u > 0) || b.q_p < 0 || b.q_v < 0) return fail(ISMPC_E_INVALID, "sweep: mass, h_des, q_u must be positive, q_p and q_v non-negative");
+        }
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(ISMPC_E_NO_DEVICE, "no HIP device visible: the ISMPC hot path has no CPU fallback");
@@ -1942,6 +1987,10 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     if (const char* zf = std::getenv("ISMPC_Z_FALLBACK")) h->z_fallback = std::atoi(zf) != 0;   // 0: flag only, no second launch
     if (const char* lp = std::getenv("ISMPC_LPI")) { const int v = std::atoi(lp); if (v == 8 || v == 16 || v == 32) { h->lpi = v; h->lpi_auto = false; } }
     if (const char* ro = std::getenv("ISMPC_ROLLOUT")) h->kernel_rollout = std::strcmp(ro, "host") != 0;
+    if (sweep) {      // one kernel shape: 16 lanes per instance, two-launch form, closed loops as one launch per tick
+        h->sweep = true; h->lpi = 16; h->lpi_auto = false; h->quad_path = true; h->dense_path = false; h->kernel_rollout = false; h->z_fallback = true;
+        h->sets.assign(params, params + K);
+    }
     DeviceGuard guard_(device);
     if (guard_.err != hipSuccess) { delete h; return fail(ISMPC_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard_.err)); }
     { hipDeviceProp_t prop; h->cus = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0; }
@@ -2026,7 +2075,110 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
     if (const char* hm = std::getenv("ISMPC_HOST_MODE")) h->host_mode = std::atoi(hm) & 3;
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
         hipEventCreate(&h->ev1) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_NO_DEVICE, "stream/event creation failed"); }
+    if (sweep) {
+        // every set's tables, built on the device (MFMA Newton-Schulz inverse of the K vertical Hessians, csrc/ismpc_sweep.hip), and one
+        // DevConst record per set: the handle's, with the set's scalars and table pointers in place of set 0's host-built ones
+        std::string serr;
+        rc = ismpc::sweep_build(params, K, h->t, c.midx, c.midy, c.e_lo, c.ne, 16, quad_R(t.p.N, 16), h->own_stream, h->sw, h->dev_allocs, serr);
+        if (rc != ISMPC_OK) { ismpc_destroy(h); return fail(rc, serr); }
+        std::vector<DevConst> cs((size_t)K, h->c);
+        for (int k = 0; k < K; ++k) {
+            DevConst& d = cs[k]; const ismpc_params& q = params[k];
+            const double eta = std::sqrt(q.g / q.h_des);
+            d.mass = q.mass; d.h_des = q.h_des; d.half_run = q.foot_width / 2; d.half_first = q.first_step_halfwidth;
+            d.q_p = q.q_p; d.q_u = q.q_u; d.q_v = q.q_v; d.z_lo = q.z_ineq_lo; d.z_hi = q.z_ineq_hi; d.eta = eta;
+            d.inv_mass = 1.0 / q.mass; d.dt_over_mass = q.mpc_dt / q.mass; d.inv_eta = 1.0 / eta;
+            d.vtab = h->sw.vtab + (size_t)k * h->sw.s_vtab; d.vqT = h->sw.vqT + (size_t)k * h->sw.s_vqT;
+            d.Wt = h->sw.Wt + (size_t)k * h->sw.s_W; d.SW = h->sw.SW + (size_t)k * h->sw.s_W;
+            d.HSt = h->sw.HSt + (size_t)k * h->sw.s_HS; d.SHSt = h->sw.SHSt + (size_t)k * h->sw.s_HS;
+            d.tailx = h->sw.tailx + (size_t)k * h->sw.s_tail; d.taily = h->sw.taily + (size_t)k * h->sw.s_tail;
+            d.Hinv = nullptr; d.W = nullptr; d.vq = nullptr; d.sets = nullptr; d.nsets = 0;
+        }
+        void* sp = nullptr;
+        if (hipMalloc(&sp, sizeof(DevConst) * (size_t)K) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_ALLOC, "sweep: set records allocation failed"); }
+        h->dev_allocs.push_back(sp);
+        if (hipMemcpy(sp, cs.data(), sizeof(DevConst) * (size_t)K, hipMemcpyHostToDevice) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_NO_DEVICE, "sweep: set records upload failed"); }
+        h->c.sets = static_cast<const DevConst*>(sp); h->c.nsets = K;
+    }
     *out = h;
+    return ISMPC_OK;
+}
+
+int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int device, ismpc_handle** out)
+{
+    return create_impl(params, 1, false, ftsp, rows, device, out);
+}
+
+int ismpc_create_sweep(const ismpc_params* params, int n_sets, const double* ftsp, int rows, int device, ismpc_handle** out)
+{
+    return create_impl(params, n_sets, true, ftsp, rows, device, out);
+}
+
+int ismpc_sweep_info(const ismpc_handle* h, int* n_sets, int* newton_iterations, int* mfma_gemm_launches, double* build_ms)
+{
+    if (!h) return fail(ISMPC_E_INVALID, "null handle");
+    if (n_sets) *n_sets = h->sweep ? h->sw.K : 1;
+    if (newton_iterations) *newton_iterations = h->sweep ? h->sw.newton_iters : 0;
+    if (mfma_gemm_launches) *mfma_gemm_launches = h->sweep ? h->sw.gemm_launches : 0;
+    if (build_ms) *build_ms = h->sweep ? (double)h->sw.build_ms : 0.0;
+    return ISMPC_OK;
+}
+
+// The device-built tables of one set against the host's long-double build of the same parameters (csrc/ismpc_tables.cpp):
+// rel_err[t] = max |device - host| / max |host| for t = 0 H^-1, 1 affine tables (U0,Ua,Ub,SU0,SUa,SUb per pattern), 2 W_p, 3 S W_p,
+// 4 Hinv S', 5 S Hinv S', 6 anticipative tails, 7 lane-group layout of the affine tables.
+int ismpc_sweep_verify_tables(ismpc_handle* h, int set, double* rel_err)
+{
+    if (!h || !rel_err) return fail(ISMPC_E_INVALID, "null argument");
+    if (!h->sweep || set < 0 || set >= h->sw.K) return fail(ISMPC_E_INVALID, "not a sweep handle, or set out of range");
+    ON_DEVICE(h);
+    ismpc::Tables t; std::string err;
+    std::vector<double> ftsp((size_t)h->t.rows * 4, 0.0);
+    // the plan as the handle captured it: midpoints are rebuilt from the footsteps, which ftsp_midpoint holds at every S+F-th row
+    for (int i = 0; i < h->t.rows; ++i) {
+        const int r = i * (h->t.p.S + h->t.p.F);
+        if (i < h->t.rows - 1) { ftsp[i*4] = h->t.midx[r]; ftsp[i*4+1] = h->t.midy[r]; ftsp[i*4+2] = h->t.midz[r]; }
+        ftsp[i*4+3] = h->t.ftsp_t[i];
+    }
+    if (h->t.rows >= 2) {            // the last footstep only enters through the blend of the row before it: recover it from two blended samples
+        const int SF = h->t.p.S + h->t.p.F, r = (h->t.rows - 2) * SF + h->t.p.S, i = h->t.rows - 1, F = h->t.p.F;
+        const std::vector<double>* col[3] = { &h->t.midx, &h->t.midy, &h->t.midz };
+        for (int cc = 0; cc < 3; ++cc) {
+            const double a = (*col[cc])[(size_t)(h->t.rows - 2) * SF];
+            ftsp[i*4+cc] = (F > 1) ? a + ((*col[cc])[r + 1] - a) * (double)F : a;
+        }
+    }
+    int rc = ismpc::build_tables(h->sets[set], ftsp.data(), h->t.rows, t, err);
+    if (rc != ISMPC_OK) return fail(rc, err);
+    const ismpc::SweepSlabs& S = h->sw;
+    const int N = t.p.N, NG = S.NG, NTq = ismpc::Tables::NT;
+    auto fetch = [&](const double* src, size_t n, std::vector<double>& dst) -> bool { dst.resize(n); return hipMemcpy(dst.data(), src, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess; };
+    auto rel = [](const std::vector<double>& d, const std::vector<double>& hst) { double e = 0, m = 0; for (size_t i = 0; i < hst.size(); ++i) { e = std::max(e, std::fabs(d[i] - hst[i])); m = std::max(m, std::fabs(hst[i])); } return m > 0 ? e / m : e; };
+    std::vector<double> d, hv;
+    if (!fetch(S.X0 + (size_t)set * S.s_mat, S.s_mat, d)) return fail(ISMPC_E_NO_DEVICE, "download failed");
+    { std::vector<double> a((size_t)N * N), b((size_t)N * N); for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) { a[(size_t)i*N+j] = d[(size_t)i*NG+j]; b[(size_t)i*N+j] = t.Hinv[(size_t)i*t.NP+j]; } rel_err[0] = rel(a, b); }
+    if (!fetch(S.vtab + (size_t)set * S.s_vtab, S.s_vtab, d)) return fail(ISMPC_E_NO_DEVICE, "download failed");
+    rel_err[1] = rel(d, t.vtab);
+    if (!fetch(S.Wt + (size_t)set * S.s_W, S.s_W, d)) return fail(ISMPC_E_NO_DEVICE, "download failed");
+    rel_err[2] = rel(d, t.Wt);
+    if (!fetch(S.SW + (size_t)set * S.s_W, S.s_W, d)) return fail(ISMPC_E_NO_DEVICE, "download failed");
+    rel_err[3] = rel(d, t.SW);
+    if (!fetch(S.HSt + (size_t)set * S.s_HS, S.s_HS, d)) return fail(ISMPC_E_NO_DEVICE, "download failed");
+    rel_err[4] = rel(d, t.HSt);
+    if (!fetch(S.SHSt + (size_t)set * S.s_HS, S.s_HS, d)) return fail(ISMPC_E_NO_DEVICE, "download failed");
+    rel_err[5] = rel(d, t.SHSt);
+    { std::vector<double> dx, dy; if (!fetch(S.tailx + (size_t)set * S.s_tail, S.s_tail, dx) || !fetch(S.taily + (size_t)set * S.s_tail, S.s_tail, dy)) return fail(ISMPC_E_NO_DEVICE, "download failed");
+      rel_err[6] = std::max(rel(dx, t.tailx), rel(dy, t.taily)); }
+    {   // the lane-group layout, against the host's re-striding of ITS vtab
+        const int R = quad_R(N, 16), lpi = 16; const size_t npp = (size_t)t.npat + 1;
+        hv.assign(npp * R * 3 * lpi * 2, 0.0);
+        for (size_t pp = 0; pp < npp; ++pp) for (int r = 0; r < R; ++r) for (int k = 0; k < 3; ++k) for (int li = 0; li < lpi; ++li) {
+            const int n = li * R + r; const size_t dst = (((pp * R + r) * 3 + k) * lpi + li) * 2;
+            hv[dst] = t.vtab[(pp * 6 + 2 * k) * NTq + n]; hv[dst + 1] = t.vtab[(pp * 6 + 2 * k + 1) * NTq + n];
+        }
+        if (!fetch(S.vqT + (size_t)set * S.s_vqT, S.s_vqT, d)) return fail(ISMPC_E_NO_DEVICE, "download failed");
+        rel_err[7] = rel(d, hv);
+    }
     return ISMPC_OK;
 }
 

@@ -1,0 +1,345 @@
+// Device-side table build for parameter sweeps of Formulation B (see ismpc_sweep.hpp).  What is computed follows
+// MPCSolver::MPCSolver / the constant part of MPCSolver::solve (reference AMR_code_DART/MPCSolver.cpp:144-160,223-259) exactly
+// as csrc/ismpc_tables.cpp restates it for one parameter set on the host; HOW differs: all sets at once, the N^3 work as
+// batched MFMA products.
+#include "ismpc_sweep.hpp"
+#include <cmath>
+#include <algorithm>
+
+namespace ismpc {
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int NT = Tables::NT;
+constexpr int PAR = 8;                  // doubles per set in SweepSlabs::par
+
+// ---- H_k (MPCSolver.cpp:258 from the closed forms of :144-154), identity on the padding, and X0 = I / bound
+__global__ __launch_bounds__(256) void sweep_init(const double* __restrict__ par, double* __restrict__ H, double* __restrict__ X, size_t smat,
+                                                  int N, int NG, double dt)
+{
+    const int set = blockIdx.x;
+    const double mass = par[set * PAR + 0], q_p = par[set * PAR + 1], q_u = par[set * PAR + 2], q_v = par[set * PAR + 3], scale = par[set * PAR + 6];
+    const double cs = dt * dt / mass, cv = dt / mass;
+    double* Hs = H + (size_t)set * smat; double* Xs = X + (size_t)set * smat;
+    for (int e = threadIdx.x; e < NG * NG; e += blockDim.x) {
+        const int i = e / NG, j = e - i * NG;
+        double v = (i == j) ? 1.0 : 0.0;
+        if (i < N && j < N) {
+            const int M = max(i, j);
+            double a = 0.0;
+            for (int k = M + 1; k < N; ++k) a += (double)(k - i) * (double)(k - j);       // S_bar_z' S_bar_z / cs^2 (exact integers)
+            const double b = (double)(N - 1 - M);                                        // S_bar_z_v' S_bar_z_v / cv^2
+            v = q_p * cs * cs * a + q_v * cv * cv * b + ((i == j) ? q_u : 0.0);
+        }
+        Hs[e] = v;
+        Xs[e] = (i == j) ? scale : 0.0;
+    }
+}
+
+// U = m S_bar_z' and Ut = m S_bar_z (unit mass; common to the sets)
+__global__ __launch_bounds__(256) void sweep_unit_s(double* __restrict__ U, double* __restrict__ Ut, int N, int NG, double dt)
+{
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < NG * NG; e += gridDim.x * blockDim.x) {
+        const int j = e / NG, k = e - j * NG;
+        U[e] = (j < k && k < N) ? (double)(k - j) * dt * dt : 0.0;          // U[j][k] = m S[k][j]
+        Ut[e] = (k < j && j < N) ? (double)(j - k) * dt * dt : 0.0;         // Ut[j][k] = m S[j][k]
+    }
+}
+
+// ---- batched C_k = op(alpha_k A_k B_k), 64 x 64 output tile per workgroup, four wavefronts of 2 x 2 MFMA tiles each,
+// operands staged through LDS as 64 x 16 / 16 x 64 panels.  MODE 0: C = 2I - A B (Newton residual), 1: C = alpha A B,
+// 2: C' = alpha A B stored TRANSPOSED with leading dimension NT, rows / columns < N only (the fallback tables' layout).
+// v_mfma_f64_16x16x4_f64: A operand lane l = A[l & 15][l >> 4], B operand lane l = B[l >> 4][l & 15], D register v of lane l =
+// D[(l >> 4) + 4 v][l & 15].
+template <int MODE>
+__global__ __launch_bounds__(256) void sweep_gemm(const double* __restrict__ A, size_t sA, const double* __restrict__ B, size_t sB,
+                                                  double* __restrict__ C, size_t sC, const double* __restrict__ par, int alpha_inv_mass, int NG, int N)
+{
+    __shared__ double As[64][17];
+    __shared__ double Bs[16][65];
+    const int set = blockIdx.z, br = blockIdx.y * 64, bc = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const double* Ap = A + (size_t)set * sA; const double* Bp = B + (size_t)set * sB;
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int ar = tid >> 2, ac = (tid & 3) * 4;            // A panel: 64 rows x 16 k, four consecutive k per thread
+    const int bk = tid >> 4, bcol = (tid & 15) * 4;         // B panel: 16 k x 64 columns, four consecutive columns per thread
+    for (int kb = 0; kb < NG; kb += 16) {
+        const double* ag = Ap + (size_t)(br + ar) * NG + kb + ac;
+        const double* bg = Bp + (size_t)(kb + bk) * NG + bc + bcol;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { As[ar][ac + t] = ag[t]; Bs[bk][bcol + t] = bg[t]; }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kq = s * 4 + (lane >> 4);
+            const double a0 = As[wr * 32 + (lane & 15)][kq], a1 = As[wr * 32 + 16 + (lane & 15)][kq];
+            const double b0 = Bs[kq][wc * 32 + (lane & 15)], b1 = Bs[kq][wc * 32 + 16 + (lane & 15)];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const double alpha = alpha_inv_mass ? 1.0 / par[set * PAR + 0] : 1.0;
+    double* Cp = C + (size_t)set * sC;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int gr = br + wr * 32 + i * 16 + (lane >> 4) + 4 * v, gc = bc + wc * 32 + j * 16 + (lane & 15);
+                double val = alpha * acc[i][j][v];
+                if (MODE == 0) val = ((gr == gc) ? 2.0 : 0.0) - val;
+                if (MODE == 2) { if (gr < N && gc < N) Cp[(size_t)gc * NT + gr] = val; }
+                else Cp[(size_t)gr * NG + gc] = val;
+            }
+}
+
+// X <- (X + X') / 2 on the N x N block (the iteration keeps X symmetric to rounding only)
+__global__ __launch_bounds__(256) void sweep_symmetrise(double* __restrict__ X, size_t smat, int N, int NG)
+{
+    double* Xs = X + (size_t)blockIdx.y * smat;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N * N; e += gridDim.x * blockDim.x) {
+        const int i = e / N, j = e - i * N;
+        if (i < j) { const double v = 0.5 * (Xs[(size_t)i * NG + j] + Xs[(size_t)j * NG + i]); Xs[(size_t)i * NG + j] = v; Xs[(size_t)j * NG + i] = v; }
+    }
+}
+
+// HSt[k][n] = M1[n][k]
+__global__ __launch_bounds__(256) void sweep_transpose_nt(const double* __restrict__ M, size_t sM, double* __restrict__ out, size_t sO, int N, int NG)
+{
+    const double* Ms = M + (size_t)blockIdx.y * sM; double* Os = out + (size_t)blockIdx.y * sO;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N * N; e += gridDim.x * blockDim.x) {
+        const int k = e / N, n = e - k * N;
+        Os[(size_t)k * NT + n] = Ms[(size_t)n * NG + k];
+    }
+}
+
+// ---- h_b = Hinv f_b, b = 0, a, b: f = f0 + z fa + zdot fb (MPCSolver.cpp:259; ismpc_tables.cpp "affine tables")
+__global__ __launch_bounds__(256) void sweep_hvec(const double* __restrict__ par, const double* __restrict__ Hinv, size_t smat, double* __restrict__ hvec,
+                                                  int N, int NG, double dt)
+{
+    __shared__ double f[3][256];
+    const int set = blockIdx.x, tid = threadIdx.x;
+    const double mass = par[set * PAR + 0], q_p = par[set * PAR + 1], q_u = par[set * PAR + 2], q_v = par[set * PAR + 3], h_des = par[set * PAR + 4], g = par[set * PAR + 7];
+    const double cs = dt * dt / mass, cv = dt / mass;
+    if (tid < 3) {
+        // S_bar_z' r (o[i] = cs sum_{k>i} (k-i) r_k) and S_bar_z_v' r (o[i] = cv sum_{k>i} r_k) as suffix sums
+        double t1 = 0.0, t2 = 0.0, acc = 0.0;
+        for (int i = N - 1; i >= 0; --i) {
+            const double k = (double)i;
+            const double tgz = -g * dt * dt * (k * (k + 1.0) / 2.0), tgv = -g * dt * k, tvec = (k + 1.0) * dt;
+            double rp, rv;                                                   // position row / velocity row right-hand sides
+            if (tid == 0) { rp = tgz - h_des; rv = tgv; } else if (tid == 1) { rp = 1.0; rv = 0.0; } else { rp = tvec; rv = 1.0; }
+            double v = q_p * (cs * t2) + q_v * (cv * acc);
+            if (tid == 0) v -= q_u * mass * g;
+            f[tid][i] = v;
+            t1 += rp; t2 += t1; acc += rv;
+        }
+    }
+    __syncthreads();
+    const double* Hs = Hinv + (size_t)set * smat;
+    for (int e = tid; e < 3 * N; e += blockDim.x) {
+        const int b = e / N, i = e - b * N;
+        double s = 0.0;
+        for (int j = 0; j < N; ++j) s = fma(Hs[(size_t)i * NG + j], f[b][j], s);
+        hvec[((size_t)set * 3 + b) * NG + i] = s;
+    }
+}
+
+// ---- one workgroup per (equality pattern, set): W_p = Hinv[:,E] (Hinv[E,E])^-1 (MPCSolver.cpp:223-243: u_i = 0 on a contiguous
+// range that depends on mpcIter only), u = -(I - W_p E') Hinv f and S u for the three right-hand sides, W_p and S W_p re-strided
+constexpr int FMAX_SWEEP = 16;
+__global__ __launch_bounds__(256) void sweep_patterns(const double* __restrict__ par, const double* __restrict__ Hinv, size_t smat, const double* __restrict__ hvec,
+                                                      const int* __restrict__ e_lo, const int* __restrict__ ne, int npat, int Fmax,
+                                                      double* __restrict__ vtab, size_t s_vtab, double* __restrict__ Wt, double* __restrict__ SW, size_t s_W,
+                                                      int N, int NG, double dt)
+{
+    __shared__ double Gm[FMAX_SWEEP][2 * FMAX_SWEEP + 1];
+    __shared__ double Wl[256][FMAX_SWEEP + 1];
+    __shared__ double hb[3][256], ub[3][256];
+    const int p = blockIdx.x, set = blockIdx.y, tid = threadIdx.x;
+    const double mass = par[set * PAR + 0];
+    const double cs = dt * dt / mass;
+    const double* Hs = Hinv + (size_t)set * smat;
+    int lo = 0, cnt = 0;
+    if (p < npat) { lo = e_lo[p]; cnt = ne[p]; }
+    for (int e = tid; e < 3 * N; e += blockDim.x) hb[e / N][e % N] = hvec[((size_t)set * 3 + e / N) * NG + e % N];
+    if (cnt > 0) {
+        // [G | I] -> [I | G^-1] by Gauss-Jordan without pivoting (G = Hinv[E,E] is symmetric positive definite)
+        for (int e = tid; e < cnt * 2 * cnt; e += blockDim.x) {
+            const int a = e / (2 * cnt), b = e - a * 2 * cnt;
+            Gm[a][b] = b < cnt ? Hs[(size_t)(lo + a) * NG + lo + b] : ((b - cnt == a) ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        for (int pv = 0; pv < cnt; ++pv) {
+            const double ip = 1.0 / Gm[pv][pv];
+            __syncthreads();
+            if (tid < 2 * cnt) Gm[pv][tid] *= ip;
+            __syncthreads();
+            for (int e = tid; e < cnt * 2 * cnt; e += blockDim.x) {
+                const int a = e / (2 * cnt), b = e - a * 2 * cnt;
+                if (a != pv && b != pv) Gm[a][b] -= Gm[a][pv] * Gm[pv][b];
+            }
+            __syncthreads();
+            if (tid < cnt && tid != pv) Gm[tid][pv] = 0.0;
+            __syncthreads();
+        }
+        for (int n = tid; n < N; n += blockDim.x)
+            for (int e = 0; e < cnt; ++e) {
+                double s = 0.0;
+                for (int a = 0; a < cnt; ++a) s = fma(Hs[(size_t)n * NG + lo + a], Gm[a][cnt + e], s);
+                Wl[n][e] = s;
+            }
+    }
+    __syncthreads();
+    for (int e = tid; e < 3 * N; e += blockDim.x) {
+        const int b = e / N, n = e - b * N;
+        double v = hb[b][n];
+        for (int q = 0; q < cnt; ++q) v = fma(-Wl[n][q], hb[b][lo + q], v);
+        ub[b][n] = (n >= lo && n < lo + cnt) ? 0.0 : -v;                    // exactly zero on the equality samples
+    }
+    __syncthreads();
+    double* vt = vtab + (size_t)set * s_vtab + (size_t)p * 6 * NT;
+    for (int e = tid; e < 3 * N; e += blockDim.x) vt[(size_t)(e / N) * NT + e % N] = ub[e / N][e % N];
+    if (tid < 3) {                                                           // S_bar_z u: o[k] = cs sum_{j<k} (k-j) u_j
+        double c1 = 0.0, c2 = 0.0;
+        for (int k = 0; k < N; ++k) { vt[(size_t)(3 + tid) * NT + k] = cs * c2; c1 += ub[tid][k]; c2 += c1; }
+    }
+    if (p < npat) {
+        double* wt = Wt + (size_t)set * s_W + (size_t)p * Fmax * NT;
+        double* sw = SW + (size_t)set * s_W + (size_t)p * Fmax * NT;
+        for (int e = tid; e < cnt * N; e += blockDim.x) wt[(size_t)(e / N) * NT + e % N] = Wl[e % N][e / N];
+        if (tid < cnt) {
+            double c1 = 0.0, c2 = 0.0;
+            for (int k = 0; k < N; ++k) { sw[(size_t)tid * NT + k] = cs * c2; c1 += Wl[k][tid]; c2 += c1; }
+        }
+    }
+}
+
+// ---- vtab -> vqT (lane-contiguous copy for the lane-group kernels; ismpc_hip.hip)
+__global__ __launch_bounds__(256) void sweep_layout(const double* __restrict__ vtab, size_t s_vtab, double* __restrict__ vqT, size_t s_vqT, int lpi, int R)
+{
+    const int p = blockIdx.x, set = blockIdx.y;
+    const double* vt = vtab + (size_t)set * s_vtab + (size_t)p * 6 * NT;
+    double* qt = vqT + (size_t)set * s_vqT + (size_t)p * R * 3 * lpi * 2;
+    for (int e = threadIdx.x; e < R * 3 * lpi * 2; e += blockDim.x) {
+        const int half = e & 1, li = (e >> 1) % lpi, k = ((e >> 1) / lpi) % 3, r = (e >> 1) / (lpi * 3);
+        const int n = li * R + r;                                            // < NT
+        qt[e] = vt[(size_t)(2 * k + half) * NT + n];
+    }
+}
+
+// ---- anticipative tails (MPCSolver.cpp:183-184, 381-383) for this set's eta = sqrt(g / h_des)
+__global__ __launch_bounds__(256) void sweep_tail(const double* __restrict__ par, const double* __restrict__ midx, const double* __restrict__ midy, int nmid,
+                                                  double* __restrict__ tailx, double* __restrict__ taily, size_t s_tail, int N, double dt)
+{
+    __shared__ double wgt[256];
+    const int set = blockIdx.y;
+    const double eta = par[set * PAR + 5];
+    if ((int)threadIdx.x < N) wgt[threadIdx.x] = eta * dt * exp(-dt * eta * (double)threadIdx.x);
+    __syncthreads();
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nmid) return;
+    double sx = 0.0, sy = 0.0;
+    if (idx + 2 * N <= nmid)
+        for (int i = 0; i < N; ++i) { sx += wgt[i] * midx[idx + N + i]; sy += wgt[i] * midy[idx + N + i]; }
+    tailx[(size_t)set * s_tail + idx] = sx; taily[(size_t)set * s_tail + idx] = sy;
+}
+
+#define SW_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return ISMPC_E_NO_DEVICE; } } while (0)
+
+int dalloc(double** p, size_t n, std::vector<void*>& allocs, std::string& err)
+{
+    void* q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); err = "sweep table allocation failed"; return ISMPC_E_ALLOC; }
+    allocs.push_back(q); *p = static_cast<double*>(q);
+    return ISMPC_OK;
+}
+
+}  // namespace
+
+int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double* midx_dev, const double* midy_dev, const int* e_lo_dev,
+                const int* ne_dev, int lpi, int R, hipStream_t s, SweepSlabs& o, std::vector<void*>& allocs, std::string& err)
+{
+    const int N = t0.p.N;
+    if (K < 1) { err = "a sweep needs at least one parameter set"; return ISMPC_E_INVALID; }
+    if (N > 128) { err = "parameter sweeps cover horizons N <= 128 (the lane-group kernels)"; return ISMPC_E_UNSUPPORTED; }
+    if (t0.Fmax > FMAX_SWEEP) { err = "parameter sweeps cover F <= 16 double-support samples"; return ISMPC_E_UNSUPPORTED; }
+    if (!t0.flat) { err = "parameter sweeps need a flat plan (every footstep at z = 0, as Controller.cpp:89-97 builds it)"; return ISMPC_E_UNSUPPORTED; }
+    const int NG = (N + 63) / 64 * 64;
+    const double dt = t0.p.mpc_dt;
+    o.K = K; o.NG = NG;
+    o.s_mat = (size_t)NG * NG; o.s_vtab = (size_t)(t0.npat + 1) * 6 * NT; o.s_vqT = (size_t)(t0.npat + 1) * R * 3 * lpi * 2;
+    o.s_W = (size_t)t0.npat * t0.Fmax * NT; o.s_HS = (size_t)N * NT; o.s_tail = (size_t)t0.nmid;
+    // per-set scalars; the Newton start 1 / bound(|H|_inf) and the iteration count from cond(H) <= bound / min(q_u, 1)
+    std::vector<double> par((size_t)K * PAR);
+    int iters = 0;
+    for (int k = 0; k < K; ++k) {
+        const ismpc_params& p = sets[k];
+        const double cs = dt * dt / p.mass, cv = dt / p.mass, n = (double)N;
+        const double bound = n * (p.q_p * cs * cs * n * n * n / 3.0 + p.q_v * cv * cv * n) + p.q_u;      // >= max row sum of H
+        par[(size_t)k * PAR + 0] = p.mass; par[(size_t)k * PAR + 1] = p.q_p; par[(size_t)k * PAR + 2] = p.q_u; par[(size_t)k * PAR + 3] = p.q_v;
+        par[(size_t)k * PAR + 4] = p.h_des; par[(size_t)k * PAR + 5] = std::sqrt(p.g / p.h_des); par[(size_t)k * PAR + 6] = 1.0 / std::max(bound, 1.0);
+        par[(size_t)k * PAR + 7] = p.g;
+        iters = std::max(iters, (int)std::ceil(std::log2(std::max(bound, 1.0) / std::min(p.q_u, 1.0))) + 8);
+    }
+    iters = std::min(iters, 96);
+    int rc;
+    if ((rc = dalloc(&o.par, par.size(), allocs, err))) return rc;
+    SW_TRY(hipMemcpyAsync(o.par, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    double** mats[] = { &o.H, &o.X0, &o.X1, &o.T, &o.M1 };
+    for (double** m : mats) if ((rc = dalloc(m, (size_t)K * o.s_mat, allocs, err))) return rc;
+    if ((rc = dalloc(&o.U, o.s_mat, allocs, err)) || (rc = dalloc(&o.Ut, o.s_mat, allocs, err))) return rc;
+    if ((rc = dalloc(&o.hvec, (size_t)K * 3 * NG, allocs, err))) return rc;
+    if ((rc = dalloc(&o.vtab, (size_t)K * o.s_vtab, allocs, err)) ||
+        (rc = dalloc(&o.vqT, (size_t)K * o.s_vqT, allocs, err)) || (rc = dalloc(&o.Wt, (size_t)K * o.s_W, allocs, err)) ||
+        (rc = dalloc(&o.SW, (size_t)K * o.s_W, allocs, err)) || (rc = dalloc(&o.HSt, (size_t)K * o.s_HS, allocs, err)) ||
+        (rc = dalloc(&o.SHSt, (size_t)K * o.s_HS, allocs, err)) || (rc = dalloc(&o.tailx, (size_t)K * o.s_tail, allocs, err)) ||
+        (rc = dalloc(&o.taily, (size_t)K * o.s_tail, allocs, err))) return rc;
+    SW_TRY(hipMemsetAsync(o.vtab, 0, (size_t)K * o.s_vtab * sizeof(double), s));
+    SW_TRY(hipMemsetAsync(o.Wt, 0, (size_t)K * o.s_W * sizeof(double), s));
+    SW_TRY(hipMemsetAsync(o.SW, 0, (size_t)K * o.s_W * sizeof(double), s));
+    SW_TRY(hipMemsetAsync(o.HSt, 0, (size_t)K * o.s_HS * sizeof(double), s));
+    SW_TRY(hipMemsetAsync(o.SHSt, 0, (size_t)K * o.s_HS * sizeof(double), s));
+    hipEvent_t e0, e1;
+    SW_TRY(hipEventCreate(&e0)); SW_TRY(hipEventCreate(&e1));
+    SW_TRY(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(sweep_init, dim3(K), dim3(256), 0, s, (const double*)o.par, o.H, o.X0, o.s_mat, N, NG, dt);
+    hipLaunchKernelGGL(sweep_unit_s, dim3(64), dim3(256), 0, s, o.U, o.Ut, N, NG, dt);
+    const dim3 ggrid(NG / 64, NG / 64, K);
+    double* X = o.X0; double* Xn = o.X1;
+    int launches = 0;
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL((sweep_gemm<0>), ggrid, dim3(256), 0, s, (const double*)o.H, o.s_mat, (const double*)X, o.s_mat, o.T, o.s_mat, (const double*)o.par, 0, NG, N);
+        hipLaunchKernelGGL((sweep_gemm<1>), ggrid, dim3(256), 0, s, (const double*)X, o.s_mat, (const double*)o.T, o.s_mat, Xn, o.s_mat, (const double*)o.par, 0, NG, N);
+        std::swap(X, Xn); launches += 2;
+    }
+    if (X != o.X0) SW_TRY(hipMemcpyAsync(o.X0, X, (size_t)K * o.s_mat * sizeof(double), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(sweep_symmetrise, dim3(16, K), dim3(256), 0, s, o.X0, o.s_mat, N, NG);
+    // inequality fallback: hs_k = Hinv S_k', shs_k = S hs_k (ismpc_tables.cpp, last block)
+    hipLaunchKernelGGL((sweep_gemm<1>), ggrid, dim3(256), 0, s, (const double*)o.X0, o.s_mat, (const double*)o.U, (size_t)0, o.M1, o.s_mat, (const double*)o.par, 1, NG, N);
+    hipLaunchKernelGGL((sweep_gemm<2>), ggrid, dim3(256), 0, s, (const double*)o.Ut, (size_t)0, (const double*)o.M1, o.s_mat, o.SHSt, o.s_HS, (const double*)o.par, 1, NG, N);
+    launches += 2;
+    hipLaunchKernelGGL(sweep_transpose_nt, dim3(16, K), dim3(256), 0, s, (const double*)o.M1, o.s_mat, o.HSt, o.s_HS, N, NG);
+    hipLaunchKernelGGL(sweep_hvec, dim3(K), dim3(256), 0, s, (const double*)o.par, (const double*)o.X0, o.s_mat, o.hvec, N, NG, dt);
+    hipLaunchKernelGGL(sweep_patterns, dim3(t0.npat + 1, K), dim3(256), 0, s, (const double*)o.par, (const double*)o.X0, o.s_mat, (const double*)o.hvec,
+                       e_lo_dev, ne_dev, t0.npat, t0.Fmax, o.vtab, o.s_vtab, o.Wt, o.SW, o.s_W, N, NG, dt);
+    hipLaunchKernelGGL(sweep_layout, dim3(t0.npat + 1, K), dim3(256), 0, s, (const double*)o.vtab, o.s_vtab, o.vqT, o.s_vqT, lpi, R);
+    hipLaunchKernelGGL(sweep_tail, dim3((t0.nmid + 255) / 256, K), dim3(256), 0, s, (const double*)o.par, midx_dev, midy_dev, t0.nmid, o.tailx, o.taily, o.s_tail, N, dt);
+    SW_TRY(hipGetLastError());
+    SW_TRY(hipEventRecord(e1, s));
+    SW_TRY(hipStreamSynchronize(s));
+    SW_TRY(hipEventElapsedTime(&o.build_ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    o.newton_iters = iters; o.gemm_launches = launches;
+    return ISMPC_OK;
+}
+
+}  // namespace ismpc
