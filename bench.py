@@ -427,8 +427,9 @@ def kernel_name_b(N, B, cus):
     return "ismpc_tick_quad<%d, %d>" % (_quad_r(N, lpi), lpi)
 
 
-def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
-    """Formulation B: `global_batch` instances sharded over the ranks; returns the result dict (rank 0) or None."""
+def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
+    """Formulation B: `global_batch` instances sharded over the ranks; returns the result dict (rank 0) or None.
+    sweep_sets > 0: a parameter sweep (ismpc_create_sweep) -- instance i runs with parameter set i % sweep_sets."""
     torch = R.torch
     from quadruped_gait_generation_ismpc_amd import workload
     from quadruped_gait_generation_ismpc_amd.distributed import shard_range, GatherPipeline
@@ -436,8 +437,13 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
     first, B = shard_range(global_batch, rank, world)
     assert global_batch % world == 0, "the bench shards the global batch evenly"
     p = q.default_params(N=N)
-    solver = q.MPCSolver(q.reference_plan(params=p), params=p, device=R.local_rank)
+    if sweep_sets > 0:
+        solver = q.MPCSolver.sweep(q.reference_plan(params=p), workload.make_sweep_params(sweep_sets, N=N), device=R.local_rank)
+    else:
+        solver = q.MPCSolver(q.reference_plan(params=p), params=p, device=R.local_rank)
     tick_in = workload.make_batch(N, B, first_instance=first)            # this rank's shard, no communication
+    if sweep_sets > 0:
+        tick_in["reserved"] = (first + np.arange(B)) % sweep_sets
     d_in = q.to_device(tick_in, R.dev)
     d_out = [torch.empty((B, 80), dtype=torch.uint8, device=R.dev) for _ in range(2)]
     cus = torch.cuda.get_device_properties(R.dev).multi_processor_count
@@ -461,7 +467,9 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
     # ---- dominant kernel alone (roofline): same inputs.  Two durations: a train of K back-to-back launches (per-launch
     # interval, event pair per region) and ONE launch between synchronisations (what rocprofv3 reports per dispatch)
     solo = solver
-    if not one_launch(N, B, cus):
+    if sweep_sets > 0:
+        pass                                                             # (a sweep step is always two launches; the fallback is idle on this batch)
+    elif not one_launch(N, B, cus):
         os.environ["ISMPC_Z_FALLBACK"] = "0"                             # the normally idle second launch switched off
         try:
             solo = q.MPCSolver(q.reference_plan(params=p), params=p, device=R.local_rank)
@@ -492,7 +500,7 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
     if rank == 0:
         value = global_batch / (wall / K)
         flops = flops_b(N) * B
-        kname = kernel_name_b(N, B, cus)
+        kname = kernel_name_b(N, B, cus) if sweep_sets == 0 else "ismpc_tick_quad<%d, 16, true>" % _quad_r(N, 16)
         res = {
             "value": value, "unit": "ticks/s (1 tick = one MPCSolver::solve = 3 QPs: vertical + x + y)",
             "ms_per_step": 1e3 * wall / K, "dtype": "f64", "qp_solves_per_s": 3.0 * value,
@@ -550,6 +558,14 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras):
             lat = sorted(lat[20:])
             res["latency_batch1_us"] = 1e6 * lat[len(lat) // 2]
             res["latency_batch1_us_p99"] = 1e6 * lat[int(0.99 * len(lat))]
+    if res is not None and sweep_sets > 0:
+        info = solver.sweep_info()
+        ng = (N + 63) // 64 * 64
+        flops = info["mfma_gemm_launches"] * 2.0 * ng ** 3 * sweep_sets
+        res["config"]["workload"] = res["config"]["workload"].replace("Formulation B (MPCSolver::solve)", f"Formulation B PARAMETER SWEEP ({sweep_sets} parameter sets: mass, h_des, q_p, q_u, q_v, foot width; instance i -> set i % {sweep_sets})")
+        res["sweep"] = dict(info, mfma_flops=flops, build_tflops=flops / (info["build_ms"] * 1e-3) / 1e12 if info["build_ms"] > 0 else None,
+                            note="tables of every set built on the device: Newton-Schulz inverse of the vertical Hessians as batched v_mfma_f64_16x16x4_f64 products "
+                                 "(csrc/ismpc_sweep.hip); build_ms = the whole build (all kernels), build_tflops = the MFMA products' flops over it")
     solver.close()
     return res
 
@@ -672,7 +688,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and batch-1 latency measurements (profiling runs: "
                                                               "every launch of the process then has the leg's own shape)")
     ap.add_argument("--only", default=None, help="run ONE leg and print it as the line: headline | config1_b1024 | config3_walk_C150 | "
-                                                  "config4_mc_C200 | shard_b8192 | a_walk_C100 | a_trot_C160 (profiling runs: one kernel shape per process)")
+                                                  "config4_mc_C200 | shard_b8192 | sweep_k64_b65536 | a_walk_C100 | a_trot_C160 (profiling runs: one kernel shape per process)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="with --only <Formulation A leg>: arithmetic type of the QP solve")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes from this process even for --gpus 1 (the launcher path of `--gpus N` as typed)")
     ap.add_argument("--force-collective", action="store_true", help="build the RCCL group and run the path's all-gather even with ONE rank "
@@ -704,6 +720,7 @@ def main():
         "headline":         lambda: leg_b(R, q, "headline_b%d" % (args.global_batch // world), args.horizon, args.global_batch, K, W, M, extras=not args.no_extras),
         "config1_b1024":    lambda: leg_b(R, q, "config1_b1024", args.horizon, 1024, K, W, M, extras=False),
         "shard_b8192":      lambda: leg_b(R, q, "shard_b8192", args.horizon, 8192, K, W, M, extras=False),
+        "sweep_k64_b65536": lambda: leg_b(R, q, "sweep_k64_b65536", args.horizon, args.global_batch, K, W, M, extras=False, sweep_sets=64),
         "config3_walk_C150": lambda dt="f64": leg_a(R, q, "config3_walk_C150", "walk_C150", A_BATCH, a_steps, 2, M, dt),
         "config4_mc_C200":  lambda dt="f64": leg_a(R, q, "config4_mc_C200", "mc_C200", A_BATCH, a_steps, 2, M, dt),
         "a_walk_C100":      lambda dt="f64": leg_a(R, q, "a_walk_C100", "walk_C100", A_BATCH, a_steps, 2, M, dt),
@@ -748,6 +765,7 @@ def main():
     if not args.no_other_configs:
         if world == 1:
             r1 = LEGS["config1_b1024"]()
+            rs = LEGS["sweep_k64_b65536"]()
             r3 = LEGS["config3_walk_C150"]()
             r3f = LEGS["config3_walk_C150"]("f32") if have_f32 else None
         r4 = LEGS["config4_mc_C200"]()
@@ -766,6 +784,10 @@ def main():
                 if cpu_b is not None:
                     r1["cpu_baseline"] = dict(cpu_b, note="same per-tick workload as the headline (Formulation B, N=100): measured once")
                 others.append(r1)
+                rs.update({"name": "north_star parameter sweep: 64 parameter sets in one batch of 65 536, N=100, fp64, one GPU (per-instance set index)", "n_gpus": 1, "steps": K, "warmup": W})
+                if cpu_b is not None:
+                    rs["cpu_baseline"] = dict(cpu_b, note="per-tick CPU cost as the headline (the oracle rebuilds its tables per set; not timed here)")
+                others.append(rs)
                 r3.update({"name": "BASELINE configs[3]: walking gait, N=150, batch 16 384, one GPU (fp64 solve)", "steps": a_steps, "warmup": 2})
                 with_cpu(r3, "config3_walk_C150"); others.append(r3)
                 if r3f is not None:

@@ -94,7 +94,7 @@ typedef struct ismpc_tick_in {
     int32_t mpc_iter;          /* WalkState::mpcIter         types.hpp:80                   */
     int32_t control_iter;      /* WalkState::controlIter                                    */
     int32_t footstep_counter;  /* WalkState::footstepCounter                                */
-    int32_t reserved;          /* keep 0                                                    */
+    int32_t reserved;          /* parameter set of the instance (ismpc_create_sweep); 0 otherwise */
 } ismpc_tick_in;               /* 72 bytes */
 
 typedef struct ismpc_tick_out {
@@ -116,6 +116,23 @@ typedef struct ismpc_handle ismpc_handle;
  * (MPCSolver.cpp:8-29 loads them but solve() never uses the values).        */
 int ismpc_create(const ismpc_params* params, const double* ftsp, int rows,
                  int device, ismpc_handle** out);
+
+/* PARAMETER SWEEPS.  BASELINE's data-parallel axis for this path is "parameter sweeps / Monte-Carlo perturbations of
+ * the same horizon": `n_sets` parameter sets that share N, S, F, M, mpc_dt, control_dt, g and lambda_gate and may differ
+ * in mass, q_p / q_u / q_v, h_des, foot_width, first_step_halfwidth and the bounds on S u (the reference re-compiles
+ * parameters.cpp:9-45 / MPCSolver.cpp:253-255 and re-runs per value).  Every set needs its own inverse of the vertical
+ * Hessian MPCSolver.cpp:258 and the tables derived from it; for a sweep they are built ON THE DEVICE for all sets at
+ * once -- Newton-Schulz inverse as batched dense products on v_mfma_f64_16x16x4_f64 (csrc/ismpc_sweep.hip).  An instance
+ * names its set in ismpc_tick_in.reserved (0 <= reserved < n_sets; anything else: ISMPC_ST_BAD_INDEX, state passed
+ * through).  Flat plans, N <= 128, F <= 16.  All entry points below work on a sweep handle.                              */
+int ismpc_create_sweep(const ismpc_params* params, int n_sets, const double* ftsp, int rows,
+                       int device, ismpc_handle** out);
+/* n_sets (1 for a plain handle), Newton-Schulz iterations run, batched MFMA product launches, table build time. */
+int ismpc_sweep_info(const ismpc_handle* h, int* n_sets, int* newton_iterations, int* mfma_gemm_launches, double* build_ms);
+/* The device-built tables of one set against the host's long-double build of the same parameters (what ismpc_create
+ * does for one set): rel_err[t] = max |device - host| / max |host| for t = 0 H^-1, 1 affine tables of the vertical stage,
+ * 2 W_p, 3 S W_p, 4 Hinv S', 5 S Hinv S', 6 anticipative tails, 7 the lane-group layout of 1.  rel_err: 8 doubles.   */
+int ismpc_sweep_verify_tables(ismpc_handle* h, int set, double* rel_err);
 
 void ismpc_destroy(ismpc_handle* h);
 

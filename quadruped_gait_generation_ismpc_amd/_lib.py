@@ -32,7 +32,7 @@ EXPORTS = ["ismpc_params_default", "ismpc_create", "ismpc_destroy", "ismpc_solve
            "ismpc_solve_batch_device", "ismpc_rollout_device", "ismpc_abi_version", "ismpc_last_error",
            "ismpc_get_params", "ismpc_midpoint_rows", "ismpc_get_midpoint", "ismpc_set_timing",
            "ismpc_last_kernel_ms", "ismpc_reserve", "ismpc_host_alloc", "ismpc_host_free", "ismpc_host_register",
-           "ismpc_host_unregister"]
+           "ismpc_host_unregister", "ismpc_create_sweep", "ismpc_sweep_info", "ismpc_sweep_verify_tables"]
 
 _lib = None
 
@@ -77,6 +77,9 @@ def load():
     lib.ismpc_host_free.argtypes = [vp]; lib.ismpc_host_free.restype = ci
     lib.ismpc_host_register.argtypes = [vp, C.c_size_t]; lib.ismpc_host_register.restype = ci
     lib.ismpc_host_unregister.argtypes = [vp]; lib.ismpc_host_unregister.restype = ci
+    lib.ismpc_create_sweep.argtypes = [vp, ci, vp, ci, ci, C.POINTER(vp)]; lib.ismpc_create_sweep.restype = ci
+    lib.ismpc_sweep_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(cd)]; lib.ismpc_sweep_info.restype = ci
+    lib.ismpc_sweep_verify_tables.argtypes = [vp, ci, vp]; lib.ismpc_sweep_verify_tables.restype = ci
     _lib = lib
     return lib
 

@@ -1789,7 +1789,7 @@ struct ismpc_handle {
     const double* vqT32 = nullptr; const double* tzgT32 = nullptr;
     bool kernel_rollout = true;   // closed loops run inside one launch (ismpc_rollout_quad); ISMPC_ROLLOUT=host: one launch per tick
     bool sweep = false;           // ismpc_create_sweep: K parameter sets, tables built on the device (csrc/ismpc_sweep.hip)
-    ismpc::SweepSlabs sw; std::vector<ismpc_params> sets;
+    ismpc::SweepSlabs sw; std::vector<ismpc_params> sets; std::vector<double> ftsp;   // (the plan as given: ismpc_sweep_verify_tables rebuilds a set on the host)
     hipStream_t last_stream = nullptr; bool used = false;   // stream of the previous launch: zmark / zstop outlive a call and are re-allocated
                                                             // only after that stream has drained (grow_sync)
 };
@@ -1989,7 +1989,7 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
     if (const char* ro = std::getenv("ISMPC_ROLLOUT")) h->kernel_rollout = std::strcmp(ro, "host") != 0;
     if (sweep) {      // one kernel shape: 16 lanes per instance, two-launch form, closed loops as one launch per tick
         h->sweep = true; h->lpi = 16; h->lpi_auto = false; h->quad_path = true; h->dense_path = false; h->kernel_rollout = false; h->z_fallback = true;
-        h->sets.assign(params, params + K);
+        h->sets.assign(params, params + K); h->ftsp.assign(ftsp, ftsp + (size_t)rows * 4);
     }
     DeviceGuard guard_(device);
     if (guard_.err != hipSuccess) { delete h; return fail(ISMPC_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard_.err)); }
@@ -2133,22 +2133,7 @@ int ismpc_sweep_verify_tables(ismpc_handle* h, int set, double* rel_err)
     if (!h->sweep || set < 0 || set >= h->sw.K) return fail(ISMPC_E_INVALID, "not a sweep handle, or set out of range");
     ON_DEVICE(h);
     ismpc::Tables t; std::string err;
-    std::vector<double> ftsp((size_t)h->t.rows * 4, 0.0);
-    // the plan as the handle captured it: midpoints are rebuilt from the footsteps, which ftsp_midpoint holds at every S+F-th row
-    for (int i = 0; i < h->t.rows; ++i) {
-        const int r = i * (h->t.p.S + h->t.p.F);
-        if (i < h->t.rows - 1) { ftsp[i*4] = h->t.midx[r]; ftsp[i*4+1] = h->t.midy[r]; ftsp[i*4+2] = h->t.midz[r]; }
-        ftsp[i*4+3] = h->t.ftsp_t[i];
-    }
-    if (h->t.rows >= 2) {            // the last footstep only enters through the blend of the row before it: recover it from two blended samples
-        const int SF = h->t.p.S + h->t.p.F, r = (h->t.rows - 2) * SF + h->t.p.S, i = h->t.rows - 1, F = h->t.p.F;
-        const std::vector<double>* col[3] = { &h->t.midx, &h->t.midy, &h->t.midz };
-        for (int cc = 0; cc < 3; ++cc) {
-            const double a = (*col[cc])[(size_t)(h->t.rows - 2) * SF];
-            ftsp[i*4+cc] = (F > 1) ? a + ((*col[cc])[r + 1] - a) * (double)F : a;
-        }
-    }
-    int rc = ismpc::build_tables(h->sets[set], ftsp.data(), h->t.rows, t, err);
+    int rc = ismpc::build_tables(h->sets[set], h->ftsp.data(), h->t.rows, t, err);
     if (rc != ISMPC_OK) return fail(rc, err);
     const ismpc::SweepSlabs& S = h->sw;
     const int N = t.p.N, NG = S.NG, NTq = ismpc::Tables::NT;

@@ -101,6 +101,19 @@ __global__ __launch_bounds__(256) void sweep_gemm(const double* __restrict__ A, 
             }
 }
 
+// R = alpha_k U - T (the residual of H M1 = alpha U, T = H M1 from the MFMA product) and M1 += D (the correction Hinv R)
+__global__ __launch_bounds__(256) void sweep_residual(const double* __restrict__ par, const double* __restrict__ U, double* __restrict__ T, size_t smat, int NG)
+{
+    const double alpha = 1.0 / par[blockIdx.y * PAR + 0];
+    double* Ts = T + (size_t)blockIdx.y * smat;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < NG * NG; e += gridDim.x * blockDim.x) Ts[e] = fma(alpha, U[e], -Ts[e]);
+}
+__global__ __launch_bounds__(256) void sweep_accumulate(double* __restrict__ M, const double* __restrict__ D, size_t smat, int NG)
+{
+    double* Ms = M + (size_t)blockIdx.y * smat; const double* Ds = D + (size_t)blockIdx.y * smat;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < NG * NG; e += gridDim.x * blockDim.x) Ms[e] += Ds[e];
+}
+
 // X <- (X + X') / 2 on the N x N block (the iteration keeps X symmetric to rounding only)
 __global__ __launch_bounds__(256) void sweep_symmetrise(double* __restrict__ X, size_t smat, int N, int NG)
 {
@@ -122,10 +135,10 @@ __global__ __launch_bounds__(256) void sweep_transpose_nt(const double* __restri
 }
 
 // ---- h_b = Hinv f_b, b = 0, a, b: f = f0 + z fa + zdot fb (MPCSolver.cpp:259; ismpc_tables.cpp "affine tables")
-__global__ __launch_bounds__(256) void sweep_hvec(const double* __restrict__ par, const double* __restrict__ Hinv, size_t smat, double* __restrict__ hvec,
-                                                  int N, int NG, double dt)
+__global__ __launch_bounds__(256) void sweep_hvec(const double* __restrict__ par, const double* __restrict__ Hinv, const double* __restrict__ H, size_t smat,
+                                                  double* __restrict__ hvec, int N, int NG, double dt)
 {
-    __shared__ double f[3][256];
+    __shared__ double f[3][256], hcur[3][256], res[3][256];
     const int set = blockIdx.x, tid = threadIdx.x;
     const double mass = par[set * PAR + 0], q_p = par[set * PAR + 1], q_u = par[set * PAR + 2], q_v = par[set * PAR + 3], h_des = par[set * PAR + 4], g = par[set * PAR + 7];
     const double cs = dt * dt / mass, cv = dt / mass;
@@ -144,14 +157,43 @@ __global__ __launch_bounds__(256) void sweep_hvec(const double* __restrict__ par
         }
     }
     __syncthreads();
-    const double* Hs = Hinv + (size_t)set * smat;
+    const double* Xs = Hinv + (size_t)set * smat; const double* Hm = H + (size_t)set * smat;
     for (int e = tid; e < 3 * N; e += blockDim.x) {
         const int b = e / N, i = e - b * N;
         double s = 0.0;
-        for (int j = 0; j < N; ++j) s = fma(Hs[(size_t)i * NG + j], f[b][j], s);
-        hvec[((size_t)set * 3 + b) * NG + i] = s;
+        for (int j = 0; j < N; ++j) s = fma(Xs[(size_t)i * NG + j], f[b][j], s);
+        hcur[b][i] = s;
     }
+    __syncthreads();
+    // two steps of iterative refinement on H h = f: h = X f carries the inverse's own error, amplified by the cancellation in
+    // X f (|X||f| >> |X f|); the corrected h only carries the rounding of the residual
+    for (int step = 0; step < 2; ++step) {
+        for (int e = tid; e < 3 * N; e += blockDim.x) {
+            const int b = e / N, i = e - b * N;
+            double r = f[b][i];
+            for (int j = 0; j < N; ++j) r = fma(-Hm[(size_t)i * NG + j], hcur[b][j], r);
+            res[b][i] = r;
+        }
+        __syncthreads();
+        double upd[3] = {0.0, 0.0, 0.0};
+        if (tid < N)
+            for (int b = 0; b < 3; ++b) { double s = 0.0; for (int j = 0; j < N; ++j) s = fma(Xs[(size_t)tid * NG + j], res[b][j], s); upd[b] = s; }
+        __syncthreads();
+        if (tid < N) for (int b = 0; b < 3; ++b) hcur[b][tid] += upd[b];
+        __syncthreads();
+    }
+    for (int e = tid; e < 3 * N; e += blockDim.x) hvec[((size_t)set * 3 + e / N) * NG + e % N] = hcur[e / N][e % N];
 }
+
+// o[k] = cs sum_{j<k} (k-j) v_j (S_bar_z applied as a double running sum), with the two running sums carried as double-double
+// (TwoSum): the plain recurrence loses digits in sums of N^2/2 terms of mixed sign that the host's long double keeps
+struct DD { double hi, lo; };
+__device__ __forceinline__ void dd_add(DD& a, double b)
+{
+    const double s = a.hi + b, bb = s - a.hi, e = (a.hi - (s - bb)) + (b - bb);
+    a.lo += e; const double t = s + a.lo; a.lo -= (t - s); a.hi = t;
+}
+__device__ __forceinline__ void dd_add(DD& a, const DD& b) { dd_add(a, b.hi); a.lo += b.lo; const double t = a.hi + a.lo; a.lo -= (t - a.hi); a.hi = t; }
 
 // ---- one workgroup per (equality pattern, set): W_p = Hinv[:,E] (Hinv[E,E])^-1 (MPCSolver.cpp:223-243: u_i = 0 on a contiguous
 // range that depends on mpcIter only), u = -(I - W_p E') Hinv f and S u for the three right-hand sides, W_p and S W_p re-strided
@@ -209,16 +251,16 @@ __global__ __launch_bounds__(256) void sweep_patterns(const double* __restrict__
     double* vt = vtab + (size_t)set * s_vtab + (size_t)p * 6 * NT;
     for (int e = tid; e < 3 * N; e += blockDim.x) vt[(size_t)(e / N) * NT + e % N] = ub[e / N][e % N];
     if (tid < 3) {                                                           // S_bar_z u: o[k] = cs sum_{j<k} (k-j) u_j
-        double c1 = 0.0, c2 = 0.0;
-        for (int k = 0; k < N; ++k) { vt[(size_t)(3 + tid) * NT + k] = cs * c2; c1 += ub[tid][k]; c2 += c1; }
+        DD c1 = {0.0, 0.0}, c2 = {0.0, 0.0};
+        for (int k = 0; k < N; ++k) { vt[(size_t)(3 + tid) * NT + k] = cs * (c2.hi + c2.lo); dd_add(c1, ub[tid][k]); dd_add(c2, c1); }
     }
     if (p < npat) {
         double* wt = Wt + (size_t)set * s_W + (size_t)p * Fmax * NT;
         double* sw = SW + (size_t)set * s_W + (size_t)p * Fmax * NT;
         for (int e = tid; e < cnt * N; e += blockDim.x) wt[(size_t)(e / N) * NT + e % N] = Wl[e % N][e / N];
         if (tid < cnt) {
-            double c1 = 0.0, c2 = 0.0;
-            for (int k = 0; k < N; ++k) { sw[(size_t)tid * NT + k] = cs * c2; c1 += Wl[k][tid]; c2 += c1; }
+            DD c1 = {0.0, 0.0}, c2 = {0.0, 0.0};
+            for (int k = 0; k < N; ++k) { sw[(size_t)tid * NT + k] = cs * (c2.hi + c2.lo); dd_add(c1, Wl[k][tid]); dd_add(c2, c1); }
         }
     }
 }
@@ -325,10 +367,15 @@ int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double*
     hipLaunchKernelGGL(sweep_symmetrise, dim3(16, K), dim3(256), 0, s, o.X0, o.s_mat, N, NG);
     // inequality fallback: hs_k = Hinv S_k', shs_k = S hs_k (ismpc_tables.cpp, last block)
     hipLaunchKernelGGL((sweep_gemm<1>), ggrid, dim3(256), 0, s, (const double*)o.X0, o.s_mat, (const double*)o.U, (size_t)0, o.M1, o.s_mat, (const double*)o.par, 1, NG, N);
+    // one step of iterative refinement on H M1 = alpha U (as for the right-hand sides in sweep_hvec): two more MFMA products
+    hipLaunchKernelGGL((sweep_gemm<1>), ggrid, dim3(256), 0, s, (const double*)o.H, o.s_mat, (const double*)o.M1, o.s_mat, o.T, o.s_mat, (const double*)o.par, 0, NG, N);
+    hipLaunchKernelGGL(sweep_residual, dim3(16, K), dim3(256), 0, s, (const double*)o.par, (const double*)o.U, o.T, o.s_mat, NG);
+    hipLaunchKernelGGL((sweep_gemm<1>), ggrid, dim3(256), 0, s, (const double*)o.X0, o.s_mat, (const double*)o.T, o.s_mat, o.X1, o.s_mat, (const double*)o.par, 0, NG, N);
+    hipLaunchKernelGGL(sweep_accumulate, dim3(16, K), dim3(256), 0, s, o.M1, (const double*)o.X1, o.s_mat, NG);
     hipLaunchKernelGGL((sweep_gemm<2>), ggrid, dim3(256), 0, s, (const double*)o.Ut, (size_t)0, (const double*)o.M1, o.s_mat, o.SHSt, o.s_HS, (const double*)o.par, 1, NG, N);
-    launches += 2;
+    launches += 4;
     hipLaunchKernelGGL(sweep_transpose_nt, dim3(16, K), dim3(256), 0, s, (const double*)o.M1, o.s_mat, o.HSt, o.s_HS, N, NG);
-    hipLaunchKernelGGL(sweep_hvec, dim3(K), dim3(256), 0, s, (const double*)o.par, (const double*)o.X0, o.s_mat, o.hvec, N, NG, dt);
+    hipLaunchKernelGGL(sweep_hvec, dim3(K), dim3(256), 0, s, (const double*)o.par, (const double*)o.X0, (const double*)o.H, o.s_mat, o.hvec, N, NG, dt);
     hipLaunchKernelGGL(sweep_patterns, dim3(t0.npat + 1, K), dim3(256), 0, s, (const double*)o.par, (const double*)o.X0, o.s_mat, (const double*)o.hvec,
                        e_lo_dev, ne_dev, t0.npat, t0.Fmax, o.vtab, o.s_vtab, o.Wt, o.SW, o.s_W, N, NG, dt);
     hipLaunchKernelGGL(sweep_layout, dim3(t0.npat + 1, K), dim3(256), 0, s, (const double*)o.vtab, o.s_vtab, o.vqT, o.s_vqT, lpi, R);

@@ -90,6 +90,36 @@ class MPCSolver:
         self.itr = 0; self.fsCount = 0; self.old_fsCount = 0; self.ct = 0
         self.xz_dot = 0.0; self.yz_dot = 0.0
 
+    @classmethod
+    def sweep(cls, ftsp_and_timings, params_list, device=0):
+        """Parameter sweep (ismpc_create_sweep): one handle for `len(params_list)` parameter sets that share the horizon and the
+        plan; instance i runs with set tick_in["reserved"][i].  Every set's tables are built on the device."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self.params_list = list(params_list)
+        self.params = self.params_list[0]
+        self.ftsp = np.ascontiguousarray(ftsp_and_timings, dtype=np.float64)
+        arr = (Params * len(self.params_list))(*self.params_list)
+        h = C.c_void_p()
+        rc = self._lib.ismpc_create_sweep(C.cast(arr, C.c_void_p), len(self.params_list), self.ftsp.ctypes.data_as(C.c_void_p),
+                                          self.ftsp.shape[0], int(device), C.byref(h))
+        if rc != 0:
+            raise IsmpcError(rc, _lib.last_error())
+        self._h = h; self.device = int(device)
+        self.itr = 0; self.fsCount = 0; self.old_fsCount = 0; self.ct = 0; self.xz_dot = 0.0; self.yz_dot = 0.0
+        return self
+
+    def sweep_info(self):
+        n, it, gl, ms = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        self._check(self._lib.ismpc_sweep_info(self._h, C.byref(n), C.byref(it), C.byref(gl), C.byref(ms)))
+        return {"n_sets": n.value, "newton_iterations": it.value, "mfma_gemm_launches": gl.value, "build_ms": ms.value}
+
+    def sweep_verify_tables(self, k):
+        """max |device - host long double| / max |host| per table kind of parameter set k (ismpc_sweep_verify_tables)."""
+        e = np.zeros(8)
+        self._check(self._lib.ismpc_sweep_verify_tables(self._h, int(k), e.ctypes.data_as(C.c_void_p)))
+        return dict(zip(("Hinv", "affine", "W", "SW", "HSt", "SHSt", "tail", "layout"), e.tolist()))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.ismpc_destroy(self._h); self._h = None

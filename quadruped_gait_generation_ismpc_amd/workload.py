@@ -90,3 +90,19 @@ def make_inst_mc(batch, seed=SEED, stream=0, C=200):
     inst["ds"] = np.round(0.6 * step).astype(np.int32); inst["F"] = -(-C // step) + 1; inst["plan"] = np.where(trot, 0, 1)
     push = np.stack([rng.uniform(-PUSH_A[0], PUSH_A[0], batch), rng.uniform(-PUSH_A[1], PUSH_A[1], batch)], 1)
     return inst, np.ascontiguousarray(push)
+
+
+def make_sweep_params(K, N=100, seed=SEED):
+    """K parameter sets for a Formulation B sweep (ismpc_create_sweep): set 0 = the reference's constants (parameters.cpp:9-45,
+    MPCSolver.cpp:253-255); the others draw mass, CoM height, the three vertical-QP weights and the foot width around them."""
+    from .solver import default_params
+    rng = np.random.Generator(np.random.Philox(key=seed + 7919))
+    out = []
+    for k in range(K):
+        p = default_params(N=N)
+        if k > 0:
+            p.mass = float(rng.uniform(35.0, 70.0)); p.h_des = float(rng.uniform(0.66, 0.72))
+            p.q_p = float(1005000.0 * rng.uniform(0.3, 3.0)); p.q_v = float(100.0 * rng.uniform(0.3, 3.0)); p.q_u = float(0.01 * rng.uniform(0.5, 2.0))
+            p.foot_width = float(rng.uniform(0.07, 0.11))
+        out.append(p)
+    return out

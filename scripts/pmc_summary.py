@@ -49,6 +49,11 @@ for T in ("F64", "F32"):
 if "SQ_INSTS_VALU" in mean:
     fp = d.get("fp_insts_f64_per_launch", 0.0) + d.get("fp_insts_f32_per_launch", 0.0)
     if fp > 0: d["fp_share_of_valu_insts"] = fp / mean["SQ_INSTS_VALU"]
+if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "SQ_BUSY_CYCLES" in mean and mean["SQ_BUSY_CYCLES"] > 0:
+    # MFMA-busy cycles are summed over the SIMDs, SQ_BUSY_CYCLES over the 32 shader engines: fraction of the kernel's cycles the matrix pipes are busy
+    d["mfma_busy_frac"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (mean["SQ_BUSY_CYCLES"] / 32.0)
+if "SQ_INSTS_VALU_MFMA_MOPS_F64" in mean:
+    d["mfma_f64_flops_per_launch"] = mean["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0      # counter_defs.yaml: MOPS x 512 = flops
 res["derived"] = d
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(d, indent=1))

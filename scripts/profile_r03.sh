@@ -7,13 +7,14 @@
 # usage: scripts/profile_r03.sh [leg ...]        default: every leg bench.py reports
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=$R/gpurun_out/profiles_r03; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-LEGS=${@:-headline shard_b8192 config1_b1024 config3_walk_C150 config3_walk_C150:f32 config4_mc_C200 config4_mc_C200:f32}
+LEGS=${@:-headline shard_b8192 config1_b1024 sweep_k64_b65536 config3_walk_C150 config3_walk_C150:f32 config4_mc_C200 config4_mc_C200:f32}
 for spec in $LEGS; do
   leg=${spec%%:*}; dt=f64; [[ $spec == *:* ]] && dt=${spec##*:}
   case $leg in
     headline)      key=headline_b65536; kern='ismpc_tick_quad<'; batch=65536; steps=40 ;;
     shard_b8192)   key=shard_b8192;     kern='ismpc_tick_quad_inline<'; batch=8192;  steps=40 ;;
     config1_b1024) key=config1_b1024;   kern='ismpc_tick_quad_inline<'; batch=1024;  steps=40 ;;
+    sweep_k64_b65536) key=sweep_k64_b65536; kern='ismpc_tick_quad<'; batch=65536; steps=40 ;;      # + the MFMA table build: pmc_sweep_gemm.json below
     *)             key=$leg;            kern='ismpc_a_tick_wave<double'; [[ $dt == f32 ]] && kern='ismpc_a_tick_wave<float'; batch=16384; steps=5 ;;   # the Monte-Carlo pre-roll runs in the OTHER precision
   esac
   [[ $dt != f64 ]] && key=${key}_$dt
@@ -33,9 +34,12 @@ for spec in $LEGS; do
   run mem TA_TA_BUSY_sum TA_FLAT_LOAD_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE
   run fetch FETCH_SIZE
   run write WRITE_SIZE
+  [[ $leg == sweep_k64_b65536 ]] && run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU
   per_step=1; [[ $leg == config4_mc_C200 && "$ISMPC_A_BUCKET" == 1 ]] && per_step=4      # opt-in: one kernel per footstep count 3..6
   python3 $R/scripts/pmc_summary.py $OUT/tmp_$key "$kern" $OUT/pmc_$key.json batch=$batch leg=\"$key\" launches_per_step=$per_step > /dev/null
   grep -E "valu_insts_per_wave|hbm_bytes_per_launch|wave_cycles_per_wave" $OUT/pmc_$key.json | tr -d '\n'; echo
+  # the sweep's table build: the batched MFMA product (sweep_gemm), same passes, its own summary
+  [[ $leg == sweep_k64_b65536 ]] && python3 $R/scripts/pmc_summary.py $OUT/tmp_$key "sweep_gemm" $OUT/pmc_sweep_gemm.json sets=64 NG=128 > /dev/null
   head -3 $OUT/${key}_kernel_stats.csv | cut -c1-160
   # the un-profiled line of the same leg, now that its PMC summary exists (roofline.achieved = executed flops / isolated launch time)
   timeout -k 10 400 $CMD > $OUT/${key}_bench_line_unprofiled.json 2> $OUT/tmp_$key/unprof.err || { tail -5 $OUT/tmp_$key/unprof.err; exit 1; }
