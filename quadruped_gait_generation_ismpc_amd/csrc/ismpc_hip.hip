@@ -171,6 +171,12 @@ __device__ __forceinline__ void sinhc_coshc(double w, double& P, double& Q)
 }
 
 // Caller bookkeeping in front of solve(): Controller.cpp:297-304 (enabled) and :310.
+// Per-launch scratch of the inequality fallback, one allocation: batch mark bytes (padded to 16), then the LIST of deferred
+// instances (batch ints) and two counters.  The per-tick kernel of launch `lid` appends to the list under counter lid & 1; the
+// fallback launch behind it walks exactly those entries (scanning 65 536 marks with 256 wavefronts cost 0.5 ms whenever
+// anything was deferred) and clears the OTHER counter for the next launch.
+__host__ __device__ inline size_t zscratch_bytes(int batch) { return (((size_t)batch + 15) & ~(size_t)15) + 4 * (size_t)batch + 16; }
+__device__ __forceinline__ int* zlist_of(unsigned char* zmark, int batch) { return reinterpret_cast<int*>(zmark + (((size_t)batch + 15) & ~(size_t)15)); }
 struct Walk { double sim; int mpc, ctl, fc; };
 __device__ __forceinline__ Walk load_walk(const DevConst& c, const ismpc_tick_in* rec, int rollout_frame)
 {
@@ -782,7 +788,7 @@ template <int R, bool FB>
 __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi, const int lane,
                                                  const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                                                  ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
-                                                 int rollout_frame, unsigned char* zmark, int launch_id)
+                                                 int rollout_frame, unsigned char* zmark, int launch_id, int* zlist = nullptr, int zbatch = 0)
 {
     constexpr int NT = ismpc::Tables::NT;
     const int N = c.N;
@@ -1043,7 +1049,10 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
     // ---- closed loop: feed back (Controller.cpp:346-348) and advance counters (:503-504)
     if constexpr (!FB) {
         if (zmark && lane == 0) zmark[gi] = deferred ? 1 : 0;
-        if (deferred && lane == 0) atomicMax(c.zflag, launch_id);
+        if (deferred && lane == 0) {
+            atomicMax(c.zflag, launch_id);
+            if (zlist) zlist[atomicAdd(zlist + zbatch + (launch_id & 1), 1)] = gi;
+        }
     }
     if (rollout_frame >= 0 && lane == 0 && !deferred && !(status & ISMPC_ST_Z_FAILED)) {   // a failed vertical solve is flagged, never fed back
         ismpc_tick_in* st = state_rw + gi;
@@ -1072,7 +1081,7 @@ void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
     const int lane = threadIdx.x & 63;
     const int gi = blockIdx.x * ISMPC_AFF_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (gi >= batch) return;
-    tick_affine_body<R, false>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+    tick_affine_body<R, false>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, zmark ? zlist_of(zmark, batch) : nullptr, batch);
 }
 
 // =====================================================================================================================
@@ -1575,7 +1584,7 @@ template <int R, int LPI, int KF, bool SW = false>
 __device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_raw, const int batch, const int lane,
                                                 const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                                                 ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
-                                                int rollout_frame, unsigned char* zmark, int launch_id, double2* __restrict__ lds_wave)
+                                                int rollout_frame, unsigned char* zmark, int launch_id, double2* __restrict__ lds_wave, int* zlist = nullptr)
 {
     const bool valid = gi_raw < batch;
     const int gi = valid ? gi_raw : batch - 1;        // tail groups recompute the last instance and store nothing
@@ -1593,7 +1602,7 @@ __device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_
     if ((lane & (LPI - 1)) == 0 && valid) {
         if (out) store_record(out + gi, o);
         if (zmark) zmark[gi] = deferred ? 1 : 0;
-        if (deferred) atomicMax(c.zflag, launch_id);
+        if (deferred) { atomicMax(c.zflag, launch_id); if (zlist) zlist[atomicAdd(zlist + batch + (launch_id & 1), 1)] = gi; }
         if (rollout_frame >= 0 && !deferred) store_feedback(c, state_rw + gi, o, s.w);
     }
     STAMP(5);                                         // stores issued
@@ -1615,7 +1624,8 @@ void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, 
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
     if (wave * IPW >= batch) return;
-    tick_group_body<R, LPI, ISMPC_KF_MAIN, SW>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
+    tick_group_body<R, LPI, ISMPC_KF_MAIN, SW>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv],
+                                               zmark ? zlist_of(zmark, batch) : nullptr);
 }
 
 // Latency variant for small batches (every wavefront resident at once): a wavefront that deferred one of its
@@ -1732,17 +1742,22 @@ void ismpc_tick_affine_fallback(const DevConst c, const ismpc_tick_in* __restric
                                 ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
                                 unsigned char* zmark, int launch_id)
 {
+    int* zl = zlist_of(zmark, batch);
+    if (blockIdx.x == 0 && threadIdx.x == 0) zl[batch + ((launch_id + 1) & 1)] = 0;       // the next launch's counter (its previous user, launch_id - 1, is done)
     if (*c.zflag != launch_id) return;
     const int lane = threadIdx.x & 63;
     const int wave0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int gi = wave0; gi < batch; gi += gridDim.x * 4)
-        if (zmark[gi]) {
+    const int ndef = min(zl[batch + (launch_id & 1)], batch);
+    for (int k = wave0; k < ndef; k += gridDim.x * 4) {
+        const int gi = __builtin_amdgcn_readfirstlane(zl[k]);
+        {
             if (SW) {
                 // one instance per wavefront: its parameter set is wave-uniform, the body runs on that set's own record
                 const int ps = __builtin_amdgcn_readfirstlane((((rollout_frame >= 0) ? state_rw : in_ro) + gi)->reserved);
                 tick_affine_body<R, true>(c.sets[ps], gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);    // (a deferred instance has a valid set)
             } else tick_affine_body<R, true>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
         }
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -1779,6 +1794,7 @@ struct ismpc_handle {
     bool timing = false; bool timed_pending = false; double last_ms = 0.0;
     int force_waves = 0;      // dense path: 4, 8 or 16 wavefronts per workgroup (0 = 16)
     unsigned char* zmark = nullptr; int zmark_cap = 0; int launch_id = 0; bool z_fallback = true;
+    int zlist_batch = -1;        // batch whose deferred-list counters (inside the zmark allocation, at batch-dependent offsets) are initialised
     int* zstop = nullptr; int zstop_cap = 0;     // in-kernel rollouts: tick at which an instance was handed to the resume launch (-1: never)
     bool dense_path = false;  // true: per-tick MFMA solve (ismpc_tick_dense); false: affine tables (ismpc_tick_affine)
     int cus = 0;              // compute units of the device (kernel variant selection); 0: never the one-launch variant
@@ -1853,12 +1869,16 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
             HIP_TRY(grow_sync(h, s));
             if (h->zmark) HIP_TRY(hipFreeAsync(h->zmark, s));
             h->zmark = nullptr; h->zmark_cap = 0;
-            HIP_TRY(hipMallocAsync((void**)&h->zmark, (size_t)batch, s));
-            h->zmark_cap = batch;
+            HIP_TRY(hipMallocAsync((void**)&h->zmark, zscratch_bytes(batch), s));
+            h->zmark_cap = batch; h->zlist_batch = -1;
+        }
+        if (h->z_fallback && h->zlist_batch != batch) {   // the two counters of the deferred list sit behind `batch` marks and `batch` entries
+            HIP_TRY(hipMemsetAsync(h->zmark + zscratch_bytes(batch) - 16, 0, 16, s));
+            h->zlist_batch = batch;
         }
         unsigned char* zm = h->z_fallback ? h->zmark : nullptr;
         const int lid = ++h->launch_id;
-        const dim3 fgrid(std::min((batch + 3) / 4, 64));
+        const dim3 fgrid(std::min((batch + 3) / 4, 256));      // the fallback walks the list of deferred instances: one wavefront each
         // default for N <= 128: several instances per wavefront (ismpc_tick_quad); ISMPC_PATH=wave keeps one per wavefront
         if (h->quad_path && h->c.N <= 128) {
             const bool small = h->lpi_auto && h->vqT32 && batch <= LPI32_BATCH;
@@ -2344,8 +2364,8 @@ int ismpc_reserve(ismpc_handle* h, int max_batch)
     if (h->z_fallback && max_batch > h->zmark_cap) {
         if (h->zmark) HIP_TRY(hipFree(h->zmark));
         h->zmark = nullptr; h->zmark_cap = 0;
-        HIP_TRY(hipMalloc((void**)&h->zmark, (size_t)max_batch));
-        h->zmark_cap = max_batch;
+        HIP_TRY(hipMalloc((void**)&h->zmark, zscratch_bytes(max_batch)));
+        h->zmark_cap = max_batch; h->zlist_batch = -1;
     }
     if (max_batch > h->zstop_cap) {
         if (h->zstop) HIP_TRY(hipFree(h->zstop));
