@@ -435,36 +435,39 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         // ---- per-row data: lane owns ZMP rows lane*RL+1 .. lane*RL+RL (row i = sample i, u index i-1).
         // ks = first mapped footstep (bits 0-3) | row state + 1 (bits 4-5: 0 upper active, 1 free, 2 lower active);
         // pn = previous active row (bits 0-15) | next active row (bits 16-31), kept for every row, active or not
-        R u[RL], w1[RL], mu[RL];
-        float inrm[RL];
-            int ks[RL], pn[RL];
-#define K1_(k_)  (ks[k_] & 15)
-#define STA_(k_) (((ks[k_] >> 4) & 3) - 1)
-#define SET_STA_(k_, s_) (ks[k_] = (ks[k_] & 15) | (((s_) + 1) << 4))
-#define PRV_(k_) (pn[k_] & 0xffff)
-#define NXT_(k_) ((int)((unsigned)pn[k_] >> 16))
-#define SET_PRV_(k_, p_) (pn[k_] = (pn[k_] & ~0xffff) | (p_))
-#define SET_NXT_(k_, n_) (pn[k_] = (pn[k_] & 0xffff) | ((n_) << 16))
+        // One packed int per row: previous active row (bits 0-8) | next active row (9-17) | row state + 1 (18-19: 0 upper active, 1 free,
+        // 2 lower active) | first mapped footstep (20-23).  The mapping weight of a row is read back from LDS (L.w1s) where it is used
+        // and the row norm of the candidate search is recomputed for violated rows only: u, the multiplier and this int are all a
+        // lane keeps per row (round 2 kept six values; the difference is what the four-rows-per-lane shapes spilled).
+        R u[RL], mu[RL];
+        int pn[RL];
+#define W1_(k_)  (L.w1s[lane * RL + (k_)])
+#define K1_(k_)  ((pn[k_] >> 20) & 15)
+#define STA_(k_) (((pn[k_] >> 18) & 3) - 1)
+#define SET_STA_(k_, s_) (pn[k_] = (pn[k_] & ~(3 << 18)) | (((s_) + 1) << 18))
+#define PRV_(k_) (pn[k_] & 0x1ff)
+#define NXT_(k_) ((pn[k_] >> 9) & 0x1ff)
+#define SET_PRV_(k_, p_) (pn[k_] = (pn[k_] & ~0x1ff) | (p_))
+#define SET_NXT_(k_, n_) (pn[k_] = (pn[k_] & ~(0x1ff << 9)) | ((n_) << 9))
+#define PN_RESET_(k_) (pn[k_] = (pn[k_] & (15 << 20)) | (1 << 18))       /* free, no links; the mapping stays */
+#define PN_PRV(v_) ((v_) & 0x1ff)
+#define PN_NXT(v_) (((v_) >> 9) & 0x1ff)
         bool ovf = false;
 #pragma unroll
         for (int k = 0; k < RL; ++k) {
             const int i = lane * RL + k + 1;
-            u[k] = R(0); mu[k] = R(0); pn[k] = 0;
+            u[k] = R(0); mu[k] = R(0); pn[k] = 1 << 18;
             if (i <= C) {
                 int qd = (int)((float)(j + i) * rstep);                          // (j + i) / step_ without the integer-division sequence
                 if (qd * step_ > j + i) --qd; else if ((qd + 1) * step_ <= j + i) ++qd;
                 int pf = qd - fc + 1; if (pf < 0) pf = 0;
                 const int rem = step_ * (fc + pf) - (j + i);
-                w1[k] = (rem > ds_) ? R(1) : (R)((double)rem * inv_ds);          // mapping(i, pf+1) = rem / ds; the next column gets 1 - w1
+                const R w1k = (rem > ds_) ? R(1) : (R)((double)rem * inv_ds);    // mapping(i, pf+1) = rem / ds; the next column gets 1 - w1
                 ovf = ovf || pf > Fi || (rem <= ds_ && pf + 1 > Fi);
                 if (pf > 15) pf = 15;
-                ks[k] = pf | (1 << 4);
-                {   // 1 / |row_i|_{H^-1} (float: it only ranks candidates): |row|^2 = dt^2 i + |M_i|^2 / Qf over the footstep columns
-                    const float w1f = (float)w1[k], w2f = 1.0f - w1f;
-                    inrm[k] = rsq_f((float)(c.dt * c.dt) * (float)i + (w2f * w2f + (pf >= 1 ? w1f * w1f : 0.0f)) * (float)iQf);
-                }
-                L.k1s[i - 1] = (unsigned char)pf; L.w1s[i - 1] = w1[k];
-            } else { w1[k] = R(1); ks[k] = 1 << 4; inrm[k] = 0.0f; }
+                pn[k] = (pf << 20) | (1 << 18);
+                L.k1s[i - 1] = (unsigned char)pf; L.w1s[i - 1] = w1k;
+            } else if (i <= WG) L.w1s[i - 1] = R(1);
         }
         if (__builtin_amdgcn_ballot_w64(ovf) != 0) status |= ISMPC_A_ST_OVERFLOW;
         // anticipative tail (quad_walk_no_plots.m:227-231)
@@ -528,7 +531,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 for (int k = 0; k < RL; ++k) { lc += u[k]; vv[k] = lc; }
                 const R bs = wave_scan_up(lc) - lc;
 #pragma unroll
-                for (int k = 0; k < RL; ++k) vv[k] = dt * (vv[k] + bs) - (w1[k] * L.fl[K1_(k)] + (R(1) - w1[k]) * L.fl[K1_(k) + 1]);
+                for (int k = 0; k < RL; ++k) { const R w1k = W1_(k); vv[k] = dt * (vv[k] + bs) - (w1k * L.fl[K1_(k)] + (R(1) - w1k) * L.fl[K1_(k) + 1]); }
                 PH(2);                                     // 2: row values
             };
 
@@ -608,7 +611,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 return cc_e;
             };
 
-            // ---- one structured solve for a whole working set (the ZMP rows in ks[], the kinematic rows in kmask / kact):
+            // ---- one structured solve for a whole working set (the ZMP rows by their state bits, the kinematic rows in kmask / kact):
             // minimiser u, f and all multipliers; leaves G(W) in L.G and prv / nxt of every row
             auto block_solve = [&](const unsigned long long kmask) __attribute__((always_inline)) {
                 LANE_FRESH();
@@ -628,7 +631,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         if (act) { lmax = max(lmax, i); lmin = min(lmin, i); }
                         nact += __builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
                         // c_i = bound_i + M_i . plan footsteps
-                        cvr[k] = act ? (sk > 0 ? zlo : zhi) + (w1[k] * L.pf[K1_(k)] + (R(1) - w1[k]) * L.pf[K1_(k) + 1]) : R(0);
+                        const R w1c = W1_(k);
+                        cvr[k] = act ? (sk > 0 ? zlo : zhi) + (w1c * L.pf[K1_(k)] + (R(1) - w1c) * L.pf[K1_(k) + 1]) : R(0);
                         if (i <= C) L.sv[i - 1] = cvr[k];                    // c of every row, for its successor
                     }
                     int run = dpp_i<0x138, 0xf>(0, wave_scan_max_i(lmax));
@@ -655,13 +659,14 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         const int p_ = PRV_(k);
                         int pk1 = -8; R pw1 = R(0), ppa = R(0), pc = R(0);                   // V_0 = 0, c_0 = 0
                         if (p_ > 0) { pk1 = L.k1s[p_ - 1]; pw1 = L.w1s[p_ - 1]; ppa = pap[p_]; pc = L.sv[p_ - 1]; }
-                        const R pw2 = (p_ > 0) ? R(1) - pw1 : R(0), w2 = R(1) - w1[k];
+                        const R w1k = W1_(k);
+                        const R pw2 = (p_ > 0) ? R(1) - pw1 : R(0), w2 = R(1) - w1k;
                         om = idt2 * rinv[i - p_];
                         dE = dt * (pap[i] - ppa); dc = cvr[k] - pc;
                         const int k1k = K1_(k);
 #pragma unroll
                         for (int r = 1; r <= F; ++r) {
-                            const R ti = (r == k1k) ? w1[k] : ((r == k1k + 1) ? w2 : R(0));
+                            const R ti = (r == k1k) ? w1k : ((r == k1k + 1) ? w2 : R(0));
                             const R tp = (r == pk1) ? pw1 : ((r == pk1 + 1) ? pw2 : R(0));
                             dth[r - 1] = ti - tp;
                         }
@@ -750,7 +755,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     const int i = lane * RL + k + 1;
                     sl[k] = R(0);
                     if (i <= C && STA_(k) != 0)
-                        sl[k] = cvr[k] - (w1[k] * L.comb[K1_(k)] + (R(1) - w1[k]) * L.comb[K1_(k) + 1]);
+                        { const R w1k = W1_(k); sl[k] = cvr[k] - (w1k * L.comb[K1_(k)] + (R(1) - w1k) * L.comb[K1_(k) + 1]); }
                     if (i <= C) L.sv[i - 1] = sl[k];
                 }
                 WAVE_LDS_SYNC();
@@ -1005,7 +1010,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 if (defer_qp) break;
                 if (cold) {
 #pragma unroll
-                    for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; SET_STA_(k, 0); mu[k] = R(0); pn[k] = 0; u[k] = (i <= C) ? t0 * ap[i - 1] : R(0); }
+                    for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; PN_RESET_(k); mu[k] = R(0); u[k] = (i <= C) ? t0 * ap[i - 1] : R(0); }
                     if (klane) fr = L.pf[lane];
                     muE = t0; qz = 0; Dd = pa2d[C]; Dee = (R)Dd;
                     for (int e = lane; e < m * m; e += 64) L.G[e] = R(0);
@@ -1035,9 +1040,13 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                             const R v = vv[k];
                             const R vl = v - zlo, vh = zhi - v;
                             const R tol = (R)NM::viol_rel * (fabs(v) + fmax(fabs(zlo), fabs(zhi))) + (R)NM::viol_abs;
-                            const R nr = (R)inrm[k];
-                            if (vl < -tol && vl * nr < cand) { cand = vl * nr; craw = vl; code = 2 * i; }
-                            if (vh < -tol && vh * nr < cand) { cand = vh * nr; craw = vh; code = 2 * i + 1; }
+                            if (vl < -tol || vh < -tol) {
+                                // 1 / |row_i|_{H^-1} (float: it only ranks candidates): |row|^2 = dt^2 i + |M_i|^2 / Qf over the footstep columns
+                                const float w1f = (float)W1_(k), w2f = 1.0f - w1f;
+                                const R nr = (R)rsq_f((float)(c.dt * c.dt) * (float)i + (w2f * w2f + (K1_(k) >= 1 ? w1f * w1f : 0.0f)) * (float)iQf);
+                                if (vl < -tol && vl * nr < cand) { cand = vl * nr; craw = vl; code = 2 * i; }
+                                if (vh < -tol && vh * nr < cand) { cand = vh * nr; craw = vh; code = 2 * i + 1; }
+                            }
                         }
                     }
                     const R fprev = dppv<0x111, 0xf, true>(R(0), fr);             // f_{r-1} (lane 0 holds f_0 = 0)
@@ -1097,7 +1106,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     int na = 0, nb = 0; R th = R(0), va = R(0), vb = R(0), vint = R(0);
                     if (isZ && qz > 0) {
                         const int pnr = at_row<int, RL>(pn, row);                  // prv / nxt are kept for every row, active or not
-                        na = pnr & 0xffff; nb = (int)((unsigned)pnr >> 16);
+                        na = PN_PRV(pnr); nb = PN_NXT(pnr);
                         if (na > 0 && lane < m) va = border_elem<R, F>(lane, L.k1s[na - 1], L.w1s[na - 1], pap[na], dt, isq);
                         if (nb > 0 && lane < m) vb = border_elem<R, F>(lane, L.k1s[nb - 1], L.w1s[nb - 1], pap[nb], dt, isq);
                         if (nb == 0) { vint = va; th = R(0); }
@@ -1134,7 +1143,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #pragma unroll
                     for (int k = 0; k < RL; ++k) {
                         const int i = lane * RL + k + 1;
-                        svl[k] = (i <= C) ? (w1[k] * L.comb[K1_(k)] + (R(1) - w1[k]) * L.comb[K1_(k) + 1]) : R(0);   // without - dt PA_i cE (split off, as in block_solve)
+                        const R w1s_ = W1_(k);
+                        svl[k] = (i <= C) ? (w1s_ * L.comb[K1_(k)] + (R(1) - w1s_) * L.comb[K1_(k) + 1]) : R(0);   // without - dt PA_i cE (split off, as in block_solve)
                         if (i <= C) L.sv[i - 1] = svl[k];
                     }
                     WAVE_LDS_SYNC();
@@ -1155,20 +1165,20 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                                 if (i == nb) r_ += sg * th;
                             }
                             rho[k] = r_;
-                            const R w2k = R(1) - w1[k];
+                            const R w1k = W1_(k), w2k = R(1) - w1k;
                             const int b1 = K1_(k);
                             R dj;                                                  // sg <row+, Z_i>
                             if (isZ) {
                                 R mm = R(0);                                       // M_p . M_i
                                 const int a1 = p_k1;
-                                if (a1 >= 1) { if (a1 == b1) mm += p_w1 * w1[k]; else if (a1 == b1 + 1) mm += p_w1 * w2k; }
-                                { const int cx = a1 + 1; if (cx == b1 && b1 >= 1) mm += p_w2 * w1[k]; else if (cx == b1 + 1) mm += p_w2 * w2k; }
+                                if (a1 >= 1) { if (a1 == b1) mm += p_w1 * w1k; else if (a1 == b1 + 1) mm += p_w1 * w2k; }
+                                { const int cx = a1 + 1; if (cx == b1 && b1 >= 1) mm += p_w2 * w1k; else if (cx == b1 + 1) mm += p_w2 * w2k; }
                                 dj = sg * (dt * dt * (R)min(row, i) + mm * iQf);
                             } else {
                                 R mk = R(0);                                       // M_i . kvec_kr
-                                if (b1 == kr) mk += w1[k];
+                                if (b1 == kr) mk += w1k;
                                 if (b1 + 1 == kr) mk += w2k;
-                                if (kr - 1 >= 1) { if (b1 == kr - 1) mk -= w1[k]; if (b1 + 1 == kr - 1) mk -= w2k; }
+                                if (kr - 1 >= 1) { if (b1 == kr - 1) mk -= w1k; if (b1 + 1 == kr - 1) mk -= w2k; }
                                 dj = sg * (-mk) * isq;
                             }
                             ddl += dj * r_;
@@ -1263,7 +1273,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #endif
                     if (lrow <= C) {
                         const int pnl = at_row<int, RL>(pn, lrow);
-                        const int pa_ = pnl & 0xffff, pb_ = (int)((unsigned)pnl >> 16);
+                        const int pa_ = PN_PRV(pnl), pb_ = PN_NXT(pnl);
                         R vl_ = R(0), wa_ = R(0), wb_ = R(0);
                         if (lane < m) {
                             vl_ = border_elem<R, F>(lane, L.k1s[lrow - 1], L.w1s[lrow - 1], pap[lrow], dt, isq);
@@ -1408,6 +1418,10 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         WAVE_LDS_SYNC();
         PH(14);                                            // 14: history, LIP update, outputs
         PH_FLUSH();
+#undef W1_
+#undef PN_RESET_
+#undef PN_PRV
+#undef PN_NXT
 #undef K1_
 #undef STA_
 #undef SET_STA_
