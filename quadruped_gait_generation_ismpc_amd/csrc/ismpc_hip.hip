@@ -1628,13 +1628,23 @@ void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, 
                                                zmark ? zlist_of(zmark, batch) : nullptr);
 }
 
+// The inequality fallback as a real CALL from the one-launch kernel: inlined there, its 200 registers' worth of state made the
+// hot path of every tick spill 180 scalar registers; called, the tick keeps the register allocation of ismpc_tick_quad and only a
+// wavefront that does defer an instance pays for the call.
+template <int RW>
+__device__ __attribute__((noinline)) void fallback_call(const DevConst* cp, int gi, int lane, const ismpc_tick_in* in_ro, ismpc_tick_in* state_rw,
+                                                        ismpc_tick_out* out, double* u_traj, int rollout_frame, unsigned char* zmark, int launch_id)
+{
+    tick_affine_body<RW, true>(*cp, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+}
+
 // Latency variant for small batches (every wavefront resident at once): a wavefront that deferred one of its
 // instances runs the inequality fallback for it right away, with all 64 lanes, so a step is ONE launch.
 template <int R, int LPI, int RW>
 __global__ __launch_bounds__(64 * ISMPC_QUAD_WAVES, 2)      // two wavefronts per SIMD (that is all a batch that takes this kernel has)
 void ismpc_tick_quad_inline(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                             ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
-                            unsigned char* zmark, int launch_id)
+                            unsigned char* zmark, int launch_id, const DevConst* __restrict__ cdev)
 {
     constexpr int IPW = 64 / LPI;
     __shared__ double2 lds_mid[ISMPC_QUAD_WAVES][wave_lds_double2<R, LPI>()];
@@ -1648,7 +1658,8 @@ void ismpc_tick_quad_inline(const DevConst c, const ismpc_tick_in* __restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     for (int q = 0; q < IPW; ++q)
         if ((m >> (LPI * q)) & 1ull)
-            tick_affine_body<RW, true>(c, wave * IPW + q, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+            fallback_call<RW>(cdev, wave * IPW + q, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);   // (the constants in memory:
+                                                                                     // taking the address of the by-value argument would move the hot path's copy to the stack)
 }
 
 // Closed loop inside ONE launch (Controller.cpp:297-310 bookkeeping, :346-348 feedback, :503-504 counters): instances are
@@ -1804,6 +1815,7 @@ struct ismpc_handle {
                               // there, slower from 3 072 on), 16 otherwise; the tables exist in both layouts
     const double* vqT32 = nullptr; const double* tzgT32 = nullptr;
     bool kernel_rollout = true;   // closed loops run inside one launch (ismpc_rollout_quad); ISMPC_ROLLOUT=host: one launch per tick
+    DevConst* c_dev = nullptr;    // the constants in device memory (the one-launch kernel's fallback call reads them there)
     bool sweep = false;           // ismpc_create_sweep: K parameter sets, tables built on the device (csrc/ismpc_sweep.hip)
     ismpc::SweepSlabs sw; std::vector<ismpc_params> sets; std::vector<double> ftsp;   // (the plan as given: ismpc_sweep_verify_tables rebuilds a set on the host)
     hipStream_t last_stream = nullptr; bool used = false;   // stream of the previous launch: zmark / zstop outlive a call and are re-allocated
@@ -1901,7 +1913,7 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
             }
             // every wavefront resident at once (<= 2 per SIMD) and a fallback to run: one launch that handles deferred instances itself
             if (zm && h->cus > 0 && waves <= 8 * h->cus) {
-#define ISMPC_QUADI(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad_inline<RR, LL, RW_>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid)
+#define ISMPC_QUADI(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad_inline<RR, LL, RW_>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid, (const DevConst*)h->c_dev)
                 ISMPC_SHAPES(ISMPC_QUADI)
 #undef ISMPC_QUADI
                 HIP_TRY(hipGetLastError());
@@ -2119,6 +2131,12 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
         h->dev_allocs.push_back(sp);
         if (hipMemcpy(sp, cs.data(), sizeof(DevConst) * (size_t)K, hipMemcpyHostToDevice) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_NO_DEVICE, "sweep: set records upload failed"); }
         h->c.sets = static_cast<const DevConst*>(sp); h->c.nsets = K;
+    }
+    {
+        void* cp = nullptr;
+        if (hipMalloc(&cp, sizeof(DevConst)) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_ALLOC, "constants allocation failed"); }
+        h->dev_allocs.push_back(cp); h->c_dev = static_cast<DevConst*>(cp);
+        if (hipMemcpy(cp, &h->c, sizeof(DevConst), hipMemcpyHostToDevice) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_NO_DEVICE, "constants upload failed"); }
     }
     *out = h;
     return ISMPC_OK;

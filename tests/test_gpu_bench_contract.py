@@ -11,12 +11,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _check_roofline(rf, ms_per_step, b_leg=False):
+def _check_roofline(rf, ms_per_step):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "executed", "algorithmic_credit"):
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma", "valu") and rf["unit"] in ("GB/s", "TFLOP/s")
     assert rf["kernel_ms"] > 0.0
-    if b_leg:
+    if "kernel_ms_train" in rf:                                                           # Formulation B legs: isolated launch and launch train
         assert 0.0 < rf["kernel_ms_train"] <= ms_per_step * 1.05                          # the dominant kernel's launch interval fits in the step
         assert rf["kernel_ms"] >= 0.9 * rf["kernel_ms_train"]                             # one launch alone is not shorter than its share of a train
     else:
@@ -57,14 +57,15 @@ def test_bench_line_contract(built_libs):
     assert d["regions"] >= 3 and d["region_ms"]["median"] * d["regions"] >= 15.0            # the timed work is not a 0.3 ms blip
     assert 0.0 <= d["config"]["active_box_fraction"] <= 1.0
     assert d["value_incl_pcie"] < d["value"] and 1.0 < d["latency_batch1_us"] < 1e4
-    _check_roofline(d["roofline"], d["ms_per_step"], b_leg=True)
+    _check_roofline(d["roofline"], d["ms_per_step"])
     _check_cpu(d["cpu_baseline"])
     assert d["value"] > 1000 * d["cpu_baseline"]["all_cores"]["value"]                     # the GPU path is not a CPU path in disguise
     names = [o["name"] for o in d["other_configs"]]
     assert any("configs[1]" in n for n in names) and any("configs[3]" in n for n in names) and any("configs[4]" in n for n in names)
+    assert any("parameter sweep" in n for n in names)
     for o in d["other_configs"]:
         for k in ("value", "unit", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline"):
             assert k in o, (o["name"], k)
-        _check_roofline(o["roofline"], o["ms_per_step"], b_leg="configs[1]" in o["name"])
+        _check_roofline(o["roofline"], o["ms_per_step"])
         _check_cpu(o["cpu_baseline"])
         assert o["value"] > 100 * o["cpu_baseline"]["all_cores"]["value"]
