@@ -158,7 +158,9 @@ def cpu_baseline(leg, unit, budget_s, sample_desc, unit_per_n=1, horizon=HORIZON
     return {"value": single, "unit": unit, "cores": 1, "kind": kind,
             "sample": f"{sample_desc}: {one['n']} {unit.split('/')[0]} in {one['seconds']:.1f} s on one pinned core, {qp}",
             "ms_per_unit": 1e3 / single,
-            "all_cores": {"value": multi, "cores": len(share), "note": "one pinned worker process per core, same sample each, rates summed"},
+            "all_cores": {"value": multi, "cores": len(share),
+                          "note": f"one pinned worker process per core, same sample each, rates summed; {len(share)} of the box's {len(aff)} CPUs by policy "
+                                  "(the GPU pool grants 16 CPUs per leased GPU): the embarrassingly parallel figure of a whole node is this rate per core x its cores"},
             "cpu_model": model, "nproc": nproc, "cpus_in_share": len(aff)}
 
 

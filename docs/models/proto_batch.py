@@ -5,7 +5,7 @@ g = V'K^-1 c (K^-1 tridiagonal: only gaps between consecutive active rows), (b) 
 apply and one suffix sum.  Compared with a dense KKT solve (proto_pdas.solve_on)."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import oracle_a as A
 import proto_pdas as PP
@@ -49,7 +49,7 @@ def block_solve(D, dt, Qf, W):
 
 if __name__ == "__main__":
     name = sys.argv[1] if len(sys.argv) > 1 else "walk_C100"
-    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"prerollA_{name}.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", f"prerollA_{name}.npz"))
     kind = int(z["gait"]); p = A.params(kind, C_=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
     sim = A.SimA(A.gait(kind, float(z["phi"]), float(z["disp_A"])), p, backend="gi")
     rng = np.random.default_rng(1)

@@ -4,7 +4,7 @@ dtype, on real pushed QPs, at the exact optimal working set: how accurate is the
 rows, worst violation of the inactive ones, multiplier signs, distance to the fp64 optimum)"""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle_a as A
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from proto_pdas import build, hybrid
@@ -97,7 +97,7 @@ def block_solve(D, cur, W, dt, Qf, eta, dtype):
 if __name__ == "__main__":
     name = sys.argv[1] if len(sys.argv) > 1 else "walk_C100"
     ntest = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"prerollA_{name}.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", f"prerollA_{name}.npz"))
     kind = int(z["gait"]); p = A.params(kind, C_=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
     sim = A.SimA(A.gait(kind, float(z["phi"]), float(z["disp_A"])), p, backend="gi")
     rng = np.random.default_rng(0)
@@ -130,7 +130,7 @@ if __name__ == "__main__":
 def first_pass_study(name, ntest=40):
     """What does the FIRST adding pass of the block warm start see?  From the equality-only point u = (b / a'a) a every violated
     row enters at once; is the structured solve on that set well posed (active rows back on their bounds, stability row met)?"""
-    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"prerollA_{name}.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", f"prerollA_{name}.npz"))
     kind = int(z["gait"]); p = A.params(kind, C_=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
     sim = A.SimA(A.gait(kind, float(z["phi"]), float(z["disp_A"])), p, backend="gi")
     rng = np.random.default_rng(1)

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Prototype (dense numpy, CPU): one closed-loop tick of one instance of a bench batch with the previous tick's working set as
 the first guess -- the situation of the slowest QPs of a device rollout (scripts/bench_rollout.py with a -DISMPC_A_DIAG build
-names them).  usage: python scripts/proto_closed.py walk_C150 <instance> <axis> <tick>"""
+names them).  usage: python docs/models/proto_closed.py walk_C150 <instance> <axis> <tick>"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "docs", "models"))
 from oracle import oracle_a as A
 from quadruped_gait_generation_ismpc_amd import workload
 from proto_pdas import build, solve_on

@@ -3,14 +3,14 @@
 (workload.make_batch_a + the oracle's per-axis QP data).  Emulates the kernel's rules -- adding passes (drop mu <= 0 with
 geometric peeling of run ends, add every violated row), drop-only passes, then Goldfarb-Idnani from the valid pair -- and
 variants of them; prints the work per QP and, with SHOW=n, the evolution of the working set of the n worst QPs.
-usage: python scripts/proto_passes.py walk_C150 [nqp] [variant ...]"""
+usage: python docs/models/proto_passes.py walk_C150 [nqp] [variant ...]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle_a as A
 from quadruped_gait_generation_ismpc_amd import workload
-sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.join(ROOT, "docs", "models"))
 from proto_pdas import build, solve_on, gi_from, runs_of
 
 

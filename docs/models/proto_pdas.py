@@ -4,7 +4,7 @@ whose multiplier went negative") does the Formulation-A QP need before the Goldf
 to fix?  Decides whether a block warm start is worth building into the wave kernel."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle_a as A
 
 def build(D, dt, Qf):
@@ -52,7 +52,7 @@ def pdas(H, g, E, b, N, lo, hi, passes):
 if __name__ == "__main__":
     name = sys.argv[1] if len(sys.argv) > 1 else "walk_C100"
     ntest = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"prerollA_{name}.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", f"prerollA_{name}.npz"))
     kind = int(z["gait"]); p = A.params(kind, C_=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
     sim = A.SimA(A.gait(kind, float(z["phi"]), float(z["disp_A"])), p, backend="gi")
     rng = np.random.default_rng(0)
@@ -146,7 +146,7 @@ def hybrid(H, g, E, b, N, lo, hi, passes, cleanup=6):
 
 
 def study(name, ntest, passes_list=(0, 1, 2, 3, 4, 6)):
-    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"prerollA_{name}.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", f"prerollA_{name}.npz"))
     kind = int(z["gait"]); p = A.params(kind, C_=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
     sim = A.SimA(A.gait(kind, float(z["phi"]), float(z["disp_A"])), p, backend="gi")
     rng = np.random.default_rng(0)
@@ -230,7 +230,7 @@ def hybrid2(H, g, E, b, N, lo, hi, C, max_add, max_drop, grow=2, cap=64, strict_
 
 
 def study2(name, ntest, cfgs=((4, 6, 2, 'all'), (4, 6, 2, 'half'), (4, 6, 2, 'q'), (4, 6, 2, 'half2'), (6, 6, 2, 'half2'))):
-    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"prerollA_{name}.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", f"prerollA_{name}.npz"))
     kind = int(z["gait"]); p = A.params(kind, C_=int(z["C"]), P=int(z["P"]), F=int(z["F"]))
     sim = A.SimA(A.gait(kind, float(z["phi"]), float(z["disp_A"])), p, backend="gi")
     rng = np.random.default_rng(0)

@@ -4,7 +4,7 @@ diagonal H, structured rows, explicit inverse of S = N' H^-1 N with rank-1 borde
 Validated here against the oracle's dense Goldfarb-Idnani on pushed closed-loop rollouts."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle_a as A
 
 

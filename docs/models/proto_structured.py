@@ -7,7 +7,7 @@ rank <= 2F+1 border handled by an m x m system (m = F + 1 + #active kinematic ro
 Checked here against a dense solve of S r = d at every step and against the oracle's solutions."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle_a as A
 
 CHECK = int(os.environ.get("CHECK", "1"))

@@ -1,4 +1,4 @@
-// Wavefront-per-QP kernel of Formulation A: the STRUCTURED dual active-set solver (scripts/proto_structured.py is its numpy
+// Wavefront-per-QP kernel of Formulation A: the STRUCTURED dual active-set solver (docs/models/proto_structured.py is its numpy
 // model).  Included by one translation unit per rows-per-lane value (ismpc_a_wave_rl{2,3,4}.hip).
 //
 // The per-axis QP of one instance (walking/quad_walk_no_plots.m:153-293):
@@ -22,7 +22,7 @@
 // symmetric, and all quantities the solver touches are step-sized: that is what lets the same code run in fp32 (Real = float:
 // right-hand sides are formed in fp64 and rounded once; the LIP update of the state stays fp64) as well as in fp64.
 //
-// Route of one solve (scripts/proto_passes.py): two exact Goldfarb-Idnani steps from the equality-only point, block
+// Route of one solve (docs/models/proto_passes.py): two exact Goldfarb-Idnani steps from the equality-only point, block
 // passes (every violated row enters at once; a negative run end leaves with the rows whose lumped multipliers stay <= 0; one
 // structured solve per pass), rounds of (exact steps, passes) while rows stay violated, Goldfarb-Idnani to the end, and a check
 // of the returned point.  Closed loops start the passes from the previous tick's working set.  An fp32 solve whose block solve
@@ -855,7 +855,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     // more than that one row.  How far: a multiplier at row i acts on u_j, j <= i, exactly like one at any later
                     // row, so the multipliers of the rows cut off a run's end, lumped onto the new end row, leave the earlier
                     // horizon as it is -- and the new end must come out positive.  A negative end therefore takes with it the
-                    // rows whose multipliers, summed from that end, are still <= 0 (scripts/proto_passes.py: 15 % less work than
+                    // rows whose multipliers, summed from that end, are still <= 0 (docs/models/proto_passes.py: 15 % less work than
                     // doubling the cut from pass to pass, worst QP 22 -> 11-18 units, no state between passes).  Never the row
                     // at the other end: a run shrinks to one row, which leaves only on its own multiplier (cutting a two-row
                     // touching point away un-pins the trajectory there, every other multiplier turns negative at once and the
