@@ -54,7 +54,7 @@ for key, name, kern in LEGS:
     out.append(f"| {name} | {d['value']:.3g} | {d['ms_per_step']:.4f} | `{r['kernel']}` | {fmt(st[0] if st else None, 1)} | {iso:.1f} / {fmt(tr * 1e3 if tr else None, 1)} | "
                f"{fmt(r.get('achieved'))} | {fmt(r.get('frac'), 3)} | {fmt(ex.get('valu_busy_frac'), 2)} | {fmt(ex.get('fp_share_of_valu_instructions'), 2)} | "
                f"{fmt(traffic / 1e6 if traffic else None, 1)} MB / {alg / 1e6:.1f} MB | {r['algorithmic_credit']['tflops']:.1f} |")
-h = line(os.path.join(P, "headline_b65536_bench_line_unprofiled.json"))
+h = line(os.path.join(P, "bench_full_line.json")) or line(os.path.join(P, "headline_b65536_bench_line_unprofiled.json"))
 extra = []
 if h:
     extra.append(f"Host entry point `ismpc_solve_batch`, 65 536 records in and out: page-locked caller buffers (zero copy) **{h.get('value_incl_pcie', 0):.3g} ticks/s** "

@@ -8,7 +8,10 @@ import numpy as np
 import quadruped_gait_generation_ismpc_amd as q
 from quadruped_gait_generation_ismpc_amd import workload
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
+if "--torch" in sys.argv:            # as bench.py: a torch CUDA context with live tensors before the host path is used
+    import torch
+    torch.cuda.set_device(0); _t = torch.zeros((B, 80), dtype=torch.uint8, device="cuda:0"); torch.cuda.synchronize()
 tin = workload.make_batch(100, B)
 p = q.default_params(N=100)
 print("ISMPC_HOST_ALLOC_FLAGS =", os.environ.get("ISMPC_HOST_ALLOC_FLAGS", "default"))
@@ -18,22 +21,28 @@ pag_out = np.zeros(B, dtype=q.TICK_OUT)
 
 
 def rate(s, a, o, reps=40):
+    if "--small-first" in sys.argv:
+        s.solve_batch(a[:64])
+    if "--device-first" in sys.argv:          # as bench.py: the handle has launched on the caller's (null) stream before
+        import torch
+        d = q.to_device(tin); [s.solve_batch_torch(d) for _ in range(50)]; torch.cuda.synchronize()
     s.solve_batch(a, out=o); s.solve_batch(a, out=o)
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter(); s.solve_batch(a, out=o); ts.append(time.perf_counter() - t0)
+    mean = 1e3 * sum(ts) / len(ts)
     ts.sort()
-    return 1e3 * ts[len(ts) // 2], 1e3 * ts[0]
+    return 1e3 * ts[len(ts) // 2], 1e3 * ts[0], mean
 
 
 for chunks in ("1", "zc_in", "zc_out", "zc_both"):
     os.environ["ISMPC_HOST_MODE"] = {"1": "0", "zc_in": "1", "zc_out": "2", "zc_both": "3"}[chunks]
     s = q.MPCSolver(q.reference_plan(params=p), params=p)
-    med, mn = rate(s, pin_in.array, pin_out.array)
-    print(f"pinned   mode={chunks:>7}: median {med:.3f} ms  min {mn:.3f} ms  -> {B / med * 1e3:.3e} ticks/s", flush=True)
+    med, mn, mean = rate(s, pin_in.array, pin_out.array)
+    print(f"pinned   mode={chunks:>7}: median {med:.3f} ms  min {mn:.3f} ms  mean {mean:.3f} ms -> {B / med * 1e3:.3e} ticks/s", flush=True)
     if chunks == "1":
-        med, mn = rate(s, tin, pag_out)
-        print(f"pageable serial   : median {med:.3f} ms  min {mn:.3f} ms  -> {B / med * 1e3:.3e} ticks/s", flush=True)
+        med, mn, mean = rate(s, tin, pag_out)
+        print(f"pageable serial   : median {med:.3f} ms  min {mn:.3f} ms  mean {mean:.3f} ms -> {B / med * 1e3:.3e} ticks/s", flush=True)
         ref = pag_out.copy()
     assert pin_out.array.tobytes() == ref.tobytes()
     s.close()

@@ -45,3 +45,10 @@ for spec in $LEGS; do
   timeout -k 10 400 $CMD > $OUT/${key}_bench_line_unprofiled.json 2> $OUT/tmp_$key/unprof.err || { tail -5 $OUT/tmp_$key/unprof.err; exit 1; }
   rm -rf $OUT/tmp_$key/*/*/*agent_info.csv
 done
+
+# the complete line (every leg, host-path extras, cpu_baseline) and the box's VALU rates, when the whole set was regenerated
+if [ $# -eq 0 ]; then
+  export ISMPC_PROFILES_DIR=$OUT
+  timeout -k 10 900 python3 $R/bench.py > $OUT/bench_full_line.json 2> $OUT/bench_full.err || { tail -5 $OUT/bench_full.err; exit 1; }
+  [ -x $R/build/valu_peak ] && $R/build/valu_peak > $OUT/valu_peak.json
+fi
