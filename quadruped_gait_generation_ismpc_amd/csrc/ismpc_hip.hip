@@ -1671,7 +1671,7 @@ void ismpc_tick_quad_inline(const DevConst c, const ismpc_tick_in* __restrict__ 
 //   FB = true (second launch, exits at once unless the first one parked something): one wavefront per parked instance
 //     resumes it at its tick, running the active-set fallback (all 64 lanes, through memory) at the ticks that need it.
 // Keeping the fallback out of the first kernel keeps its register budget that of the tick itself.
-template <int R, int LPI, int RW, bool FB>
+template <int R, int LPI, int RW, bool FB, bool SW = false>
 __global__ __launch_bounds__(64 * ISMPC_QUAD_WAVES, 2)
 void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* __restrict__ traj, int batch, int first_frame, int ticks,
                         int* __restrict__ stop_tick, int launch_id)
@@ -1694,6 +1694,7 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
         s.w.sim = rec->simulation_time; s.w.mpc = rec->mpc_iter; s.w.ctl = rec->control_iter; s.w.fc = rec->footstep_counter;
         s.x = rec->com_pos[0]; s.y = rec->com_pos[1]; s.z = rec->com_pos[2];
         s.xd = rec->com_vel[0]; s.yd = rec->com_vel[1]; s.zd = rec->com_vel[2]; s.ps = 0;
+        if (SW) { const int ps = rec->reserved; s.ps = (ps >= 0 && ps < c.nsets) ? ps : -1; }     // sweep handles: the instance's parameter set
         bool alive = true;                                              // FB = false: false once the instance is parked
         int stopped = -1;
         for (int t = t0; t < ticks; ++t) {
@@ -1703,7 +1704,7 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
             if (s.w.fc >= 0 && s.w.fc < c.rows && s.w.sim >= c.ftsp_t[s.w.fc] - 1) { s.w.ctl = 0; s.w.mpc = 0; s.w.fc = s.w.fc + 1; }
             s.w.sim = (double)frame;
             QOut o;
-            const bool def = tick_group_core<R, LPI, ISMPC_KF_ROLLOUT>(c, lane, s, o, nullptr, lds_mid[wv]);
+            const bool def = tick_group_core<R, LPI, ISMPC_KF_ROLLOUT, SW>(c, lane, s, o, nullptr, lds_mid[wv]);
             const bool park = def && alive;
             if (li == 0 && valid && alive && !def && traj) store_record(traj + (size_t)t * batch + gi, o);
             // a deferred instance: its pre-tick state goes to memory (FB = false: to stay there; FB = true: for the fallback body)
@@ -1723,7 +1724,9 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
             if constexpr (FB) {
                 if (__builtin_amdgcn_ballot_w64(def && valid) != 0ull) {
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                    tick_affine_body<RW, true>(c, gi, lane, nullptr, state, traj ? traj + (size_t)t * batch : nullptr, nullptr, frame, nullptr, 0);
+                    // (FB: one instance per wavefront, its set is wave-uniform and valid -- an invalid one never defers)
+                    tick_affine_body<RW, true>(SW ? c.sets[__builtin_amdgcn_readfirstlane(max(s.ps, 0))] : c, gi, lane, nullptr, state,
+                                               traj ? traj + (size_t)t * batch : nullptr, nullptr, frame, nullptr, 0);
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     const volatile ismpc_tick_in* vr = rec;
                     s.x = vr->com_pos[0]; s.y = vr->com_pos[1]; s.z = vr->com_pos[2];
@@ -2019,8 +2022,8 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
     if (const char* zf = std::getenv("ISMPC_Z_FALLBACK")) h->z_fallback = std::atoi(zf) != 0;   // 0: flag only, no second launch
     if (const char* lp = std::getenv("ISMPC_LPI")) { const int v = std::atoi(lp); if (v == 8 || v == 16 || v == 32) { h->lpi = v; h->lpi_auto = false; } }
     if (const char* ro = std::getenv("ISMPC_ROLLOUT")) h->kernel_rollout = std::strcmp(ro, "host") != 0;
-    if (sweep) {      // one kernel shape: 16 lanes per instance, two-launch form, closed loops as one launch per tick
-        h->sweep = true; h->lpi = 16; h->lpi_auto = false; h->quad_path = true; h->dense_path = false; h->kernel_rollout = false; h->z_fallback = true;
+    if (sweep) {      // one kernel shape: 16 lanes per instance, two-launch form
+        h->sweep = true; h->lpi = 16; h->lpi_auto = false; h->quad_path = true; h->dense_path = false; h->z_fallback = true;
         h->sets.assign(params, params + K); h->ftsp.assign(ftsp, ftsp + (size_t)rows * 4);
     }
     DeviceGuard guard_(device);
@@ -2333,7 +2336,15 @@ int ismpc_rollout_device(ismpc_handle* h, int batch, ismpc_tick_in* state_dev, i
 #define ISMPC_ROLL(RR, LL, RW_) do { \
         hipLaunchKernelGGL((ismpc_rollout_quad<RR, LL, RW_, false>), qgrid, qblock, 0, s, cq, state_dev, traj_dev, batch, first_frame, ticks, h->zstop, lid); \
         hipLaunchKernelGGL((ismpc_rollout_quad<RR, LL, RW_, true>), rgrid, qblock, 0, s, cq, state_dev, traj_dev, batch, first_frame, ticks, h->zstop, lid); } while (0)
+        if (h->sweep) {
+#define ISMPC_ROLLS(RR, RW_) do { \
+        hipLaunchKernelGGL((ismpc_rollout_quad<RR, 16, RW_, false, true>), qgrid, qblock, 0, s, cq, state_dev, traj_dev, batch, first_frame, ticks, h->zstop, lid); \
+        hipLaunchKernelGGL((ismpc_rollout_quad<RR, 16, RW_, true, true>), rgrid, qblock, 0, s, cq, state_dev, traj_dev, batch, first_frame, ticks, h->zstop, lid); } while (0)
+            if (RQ == 4) ISMPC_ROLLS(4, 1); else if (RQ == 7) ISMPC_ROLLS(7, 2); else ISMPC_ROLLS(8, 2);
+#undef ISMPC_ROLLS
+        } else {
         ISMPC_SHAPES(ISMPC_ROLL)
+        }
 #undef ISMPC_ROLL
         HIP_TRY(hipGetLastError());
     } else {

@@ -143,3 +143,34 @@ def test_sweep_closed_loop_and_vertical_fallback(q):
         assert rel[ok].max() <= TOL
         assert (out["status"][m][ok] == ref["status"][ok]).all()
     s.close()
+
+
+def test_sweep_in_kernel_rollout_is_bitwise_the_per_tick_loop(q, monkeypatch):
+    """Closed loops on a sweep handle run inside ONE launch like the plain handle's (ismpc_rollout_quad<.., SW>): byte-identical to one
+    launch per tick (ISMPC_ROLLOUT=host) -- also for sets whose tight bound on S u parks instances for the resume launch."""
+    import torch
+    from oracle import oracle as O
+    ps = sweep_params(q, 6, seed=5)
+    ps[4].z_ineq_hi = 4.6; ps[5].z_ineq_hi = 4.2
+    plan = q.reference_plan(params=ps[0])
+    monkeypatch.delenv("ISMPC_ROLLOUT", raising=False)
+    a = q.MPCSolver.sweep(plan, ps)
+    monkeypatch.setenv("ISMPC_ROLLOUT", "host")
+    b = q.MPCSolver.sweep(plan, ps)
+    monkeypatch.delenv("ISMPC_ROLLOUT", raising=False)
+    B, ticks = 41, 220
+    recs = np.repeat(O.initial_state().view(q.TICK_IN), B)
+    rng = np.random.default_rng(4)
+    recs["com_pos"][1:, :2] += rng.uniform(-0.004, 0.004, (B - 1, 2)); recs["com_vel"][1:, :2] += rng.uniform(-0.02, 0.02, (B - 1, 2))
+    recs["reserved"] = np.arange(B) % 6
+    recs["reserved"][7] = 9                                             # an unknown set: flagged every tick, state passed through
+    sa, sb = q.to_device(recs), q.to_device(recs)
+    ta = a.rollout_torch(sa, 0, ticks); tb = b.rollout_torch(sb, 0, ticks)
+    torch.cuda.synchronize()
+    assert torch.equal(ta, tb) and torch.equal(sa, sb)
+    out = q.from_device(ta, q.TICK_OUT)
+    assert ((out["status"][:, 7] & q.ST_BAD_INDEX) != 0).all() and np.array_equal(out["com_pos"][-1, 7], recs["com_pos"][7])
+    tight = np.isin(recs["reserved"], (4, 5)) & (np.arange(B) != 7)
+    assert ((out["status"][:, tight] & q.ST_Z_INEQ_ACTIVE) != 0).any(axis=0).all()       # those instances went through the resume launch
+    assert ((out["status"] & q.ST_Z_FAILED) == 0).all()
+    a.close(); b.close()
