@@ -755,3 +755,33 @@ def test_other_streams_and_harder_pushes_against_oracle(FA, name, stream, scale,
                 assert abs(out["f0"][i, ax] - r["f0"][ax]) <= (1e-7 if precision == "f64" else 2e-5), (i, ax)
                 assert abs(out["vel_after"][i, ax] - r["vel_after"][ax]) <= (1e-6 if precision == "f64" else 5e-6), (i, ax)
     gen.close()
+
+
+def test_entry_points_run_on_the_handles_device_whatever_is_current(FA):
+    """Every entry point runs on the handle's device and leaves the caller's current device as it found it -- also the swing-foot
+    launches behind a tick (round 2 ran those on whatever device was current).  Needs two GPUs: skipped on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the pool leases one)")
+    g = FA.default_gait(FA.WALK, np.pi / 4, 0.1)
+    fp0, ce = FA.plan(g)
+    torch.cuda.set_device(1)
+    gen = FA.GaitGenerator(FA.default_params(FA.WALK), ce, device=0)          # created while device 1 is current
+    assert torch.cuda.current_device() == 1
+    st = q_to_dev(gen.initial_state(g.disp_C, batch=2))                      # cuda:0
+    feet = gen.feet_init_torch(g, fp0, batch=2, device="cuda:0")
+    with torch.cuda.device(0):
+        stream0 = torch.cuda.current_stream().cuda_stream
+    traj = torch.empty((30, 2, 80), dtype=torch.uint8, device="cuda:0")
+    import ctypes as C
+    rc = FA._l().ismpc_a_rollout_feet_device(gen._h, 2, C.c_void_p(st.data_ptr()), 30, C.c_void_p(traj.data_ptr()), C.c_void_p(feet.data_ptr()),
+                                            C.c_void_p(stream0) if stream0 else None)
+    assert rc == 0 and torch.cuda.current_device() == 1
+    torch.cuda.synchronize(0)
+    out = q_from_dev(traj, FA.OUT_A)
+    assert (out["status"] == 0).all()
+    torch.cuda.set_device(0)
+    ref = FA.GaitGenerator(FA.default_params(FA.WALK), ce, device=0)
+    st2 = q_to_dev(ref.initial_state(g.disp_C, batch=2)); feet2 = ref.feet_init_torch(g, fp0, batch=2)
+    t2 = ref.rollout_feet_torch(st2, feet2, 30); torch.cuda.synchronize()
+    assert torch.equal(t2, traj) and torch.equal(feet2, feet)
