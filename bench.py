@@ -315,7 +315,10 @@ class RegionEvents:
 def load_pmc(leg):
     """profiles/r03/pmc_<leg>.json (scripts/profile_r03.sh + scripts/pmc_summary.py): counters of the dominant kernel,
     mean per launch, collected on exactly this leg's batch -- never scaled from another batch."""
-    path = os.path.join(os.environ.get("ISMPC_PROFILES_DIR") or PROFILES, f"pmc_{leg}.json")
+    base = os.environ.get("ISMPC_PROFILES_DIR") or PROFILES
+    path = os.path.join(base, f"pmc_{leg}.json")
+    if not os.path.exists(path) and leg.startswith("headline_b"):        # the headline sharded over N ranks: the per-GPU shard's own pass
+        path = os.path.join(base, f"pmc_shard_b{leg[len('headline_b'):]}.json")
     if not os.path.exists(path):
         return None
     try:
@@ -346,7 +349,7 @@ def roofline(leg, kernel, kernel_ms, batch, dtype, alg_flops, alg_bytes, extra=N
     c, d = j.get("counters_mean_per_launch", {}), j.get("derived", {})
     per_step = float(j.get("launches_per_step", 1))
     fl64, fl32 = d.get("flops_f64_per_launch"), d.get("flops_f32_per_launch")
-    ex = {"source": f"profiles/r03/pmc_{leg}.json"}
+    ex = {"source": "profiles/r03/pmc_" + str(j.get("leg", leg)) + ".json"}
     if fl64 is not None and fl32 is not None and fl64 + fl32 > 0:
         flops = (fl64 + fl32) * per_step
         rf["achieved"] = flops / (kernel_ms * 1e-3) / 1e12
@@ -703,7 +706,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and batch-1 latency measurements (profiling runs: "
                                                               "every launch of the process then has the leg's own shape)")
     ap.add_argument("--only", default=None, help="run ONE leg and print it as the line: headline | config1_b1024 | config3_walk_C150 | "
-                                                  "config4_mc_C200 | shard_b8192 | sweep_k64_b65536 | a_walk_C100 | a_trot_C160 (profiling runs: one kernel shape per process)")
+                                                  "config4_mc_C200 | shard_b8192 | shard_b16384 | shard_b32768 | sweep_k64_b65536 | a_walk_C100 | a_trot_C160 (profiling runs: one kernel shape per process)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="with --only <Formulation A leg>: arithmetic type of the QP solve")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes from this process even for --gpus 1 (the launcher path of `--gpus N` as typed)")
     ap.add_argument("--force-collective", action="store_true", help="build the RCCL group and run the path's all-gather even with ONE rank "
@@ -735,6 +738,8 @@ def main():
         "headline":         lambda: leg_b(R, q, "headline_b%d" % (args.global_batch // world), args.horizon, args.global_batch, K, W, M, extras=not args.no_extras),
         "config1_b1024":    lambda: leg_b(R, q, "config1_b1024", args.horizon, 1024, K, W, M, extras=False),
         "shard_b8192":      lambda: leg_b(R, q, "shard_b8192", args.horizon, 8192, K, W, M, extras=False),
+        "shard_b16384":     lambda: leg_b(R, q, "shard_b16384", args.horizon, 16384, K, W, M, extras=False),    # the per-GPU shards of the headline at N = 4, 2
+        "shard_b32768":     lambda: leg_b(R, q, "shard_b32768", args.horizon, 32768, K, W, M, extras=False),
         "sweep_k64_b65536": lambda: leg_b(R, q, "sweep_k64_b65536", args.horizon, args.global_batch, K, W, M, extras=False, sweep_sets=64),
         "config3_walk_C150": lambda dt="f64": leg_a(R, q, "config3_walk_C150", "walk_C150", A_BATCH, a_steps, 2, M, dt),
         "config4_mc_C200":  lambda dt="f64": leg_a(R, q, "config4_mc_C200", "mc_C200", A_BATCH, a_steps, 2, M, dt),
