@@ -2270,7 +2270,12 @@ int ismpc_solve_batch(ismpc_handle* h, int batch, const ismpc_tick_in* in_host, 
             return ISMPC_OK;
         }
     }
-    const bool zero_copy = h->host_mode != 0 && !h->dense_path && host_is_pinned(in_host) && host_is_pinned(out_host);
+    // zero copy needs device-visible addresses for the caller's records (page-locked AND mapped: hipHostMalloc / hipHostRegister give
+    // both under unified addressing); anything else -- also a registration without a device mapping -- takes the staged path
+    const ismpc_tick_in* zc_in = nullptr; ismpc_tick_out* zc_out = nullptr;
+    bool zero_copy = h->host_mode != 0 && !h->dense_path && host_is_pinned(in_host) && host_is_pinned(out_host);
+    if (zero_copy && (hipHostGetDevicePointer((void**)&zc_in, const_cast<ismpc_tick_in*>(in_host), 0) != hipSuccess ||
+                      hipHostGetDevicePointer((void**)&zc_out, out_host, 0) != hipSuccess)) { (void)hipGetLastError(); zero_copy = false; }
     if (batch > h->st_cap && !(zero_copy && h->host_mode == 3)) {      // device staging (not needed when both sides are in place)
         if (h->st_in) (void)hipFree(h->st_in);
         if (h->st_out) (void)hipFree(h->st_out);
@@ -2290,9 +2295,9 @@ int ismpc_solve_batch(ismpc_handle* h, int batch, const ismpc_tick_in* in_host, 
     if (zero_copy) {
         const ismpc_tick_in* din = h->st_in; ismpc_tick_out* dout = h->st_out;
         hipStream_t s = h->own_stream;
-        if (h->host_mode & 1) HIP_TRY(hipHostGetDevicePointer((void**)&din, const_cast<ismpc_tick_in*>(in_host), 0));
+        if (h->host_mode & 1) din = zc_in;
         else HIP_TRY(hipMemcpyAsync(h->st_in, in_host, sizeof(ismpc_tick_in) * (size_t)batch, hipMemcpyHostToDevice, s));
-        if (h->host_mode & 2) HIP_TRY(hipHostGetDevicePointer((void**)&dout, out_host, 0));
+        if (h->host_mode & 2) dout = zc_out;
         const int rc = ismpc_solve_batch_device(h, batch, din, dout, nullptr, s);
         if (rc != ISMPC_OK) return rc;
         if (!(h->host_mode & 2)) HIP_TRY(hipMemcpyAsync(out_host, h->st_out, sizeof(ismpc_tick_out) * (size_t)batch, hipMemcpyDeviceToHost, s));

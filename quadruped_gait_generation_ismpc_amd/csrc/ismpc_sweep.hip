@@ -350,8 +350,9 @@ int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double*
     SW_TRY(hipMemsetAsync(o.SW, 0, (size_t)K * o.s_W * sizeof(double), s));
     SW_TRY(hipMemsetAsync(o.HSt, 0, (size_t)K * o.s_HS * sizeof(double), s));
     SW_TRY(hipMemsetAsync(o.SHSt, 0, (size_t)K * o.s_HS * sizeof(double), s));
-    hipEvent_t e0, e1;
-    SW_TRY(hipEventCreate(&e0)); SW_TRY(hipEventCreate(&e1));
+    struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev;
+    SW_TRY(hipEventCreate(&ev.a)); SW_TRY(hipEventCreate(&ev.b));
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     SW_TRY(hipEventRecord(e0, s));
     hipLaunchKernelGGL(sweep_init, dim3(K), dim3(256), 0, s, (const double*)o.par, o.H, o.X0, o.s_mat, N, NG, dt);
     hipLaunchKernelGGL(sweep_unit_s, dim3(64), dim3(256), 0, s, o.U, o.Ut, N, NG, dt);
@@ -384,7 +385,6 @@ int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double*
     SW_TRY(hipEventRecord(e1, s));
     SW_TRY(hipStreamSynchronize(s));
     SW_TRY(hipEventElapsedTime(&o.build_ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     o.newton_iters = iters; o.gemm_launches = launches;
     return ISMPC_OK;
 }

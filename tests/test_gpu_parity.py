@@ -368,6 +368,28 @@ def test_zero_copy_host_path_is_bitwise_the_device_path(q, batch, over):
     pin_in.free(); pin_out.free()
 
 
+def test_host_registered_caller_buffers(q):
+    """ismpc_host_register pins buffers the caller already owns (plain numpy arrays here): same zero-copy path, same bytes; after
+    ismpc_host_unregister the very same arrays take the staged path, same bytes again."""
+    import ctypes as C
+    from quadruped_gait_generation_ismpc_amd import workload, _lib
+    lib = _lib.load()
+    s = solver_for(q, 100, "auto")
+    B = 20000
+    tin = workload.make_batch(100, B, seed=6)
+    out = np.zeros(B, dtype=q.TICK_OUT)
+    ref = s.solve_batch(tin).copy()
+    assert lib.ismpc_host_register(tin.ctypes.data_as(C.c_void_p), tin.nbytes) == 0, _lib.last_error()
+    assert lib.ismpc_host_register(out.ctypes.data_as(C.c_void_p), out.nbytes) == 0, _lib.last_error()
+    try:
+        a = s.solve_batch(tin, out=out).copy()
+    finally:
+        assert lib.ismpc_host_unregister(tin.ctypes.data_as(C.c_void_p)) == 0 and lib.ismpc_host_unregister(out.ctypes.data_as(C.c_void_p)) == 0
+    out[:] = 0
+    b = s.solve_batch(tin, out=out).copy()
+    assert a.tobytes() == ref.tobytes() and b.tobytes() == ref.tobytes()
+
+
 @pytest.mark.parametrize("batch", [8192, 65536])
 def test_bitwise_reproducible_across_launch_variants_of_one_path(q, batch):
     """Same inputs, same path: byte-identical records run to run (8 192 takes the one-launch kernel, 65 536 the two-launch form)."""
