@@ -67,12 +67,25 @@ __global__ __launch_bounds__(256) void sweep_gemm(const double* __restrict__ A, 
         for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
     const int ar = tid >> 2, ac = (tid & 3) * 4;            // A panel: 64 rows x 16 k, four consecutive k per thread
     const int bk = tid >> 4, bcol = (tid & 15) * 4;         // B panel: 16 k x 64 columns, four consecutive columns per thread
-    for (int kb = 0; kb < NG; kb += 16) {
-        const double* ag = Ap + (size_t)(br + ar) * NG + kb + ac;
-        const double* bg = Bp + (size_t)(kb + bk) * NG + bc + bcol;
+    // software pipeline: the next panels travel from L2 to registers while the matrix cores work on the ones in LDS (one wavefront
+    // per SIMD at these grid sizes: nothing else would hide the load latency)
+    double ra[4], rb[4];
+    {
+        const double* ag = Ap + (size_t)(br + ar) * NG + ac;
+        const double* bg = Bp + (size_t)bk * NG + bc + bcol;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { As[ar][ac + t] = ag[t]; Bs[bk][bcol + t] = bg[t]; }
+        for (int t = 0; t < 4; ++t) { ra[t] = ag[t]; rb[t] = bg[t]; }
+    }
+    for (int kb = 0; kb < NG; kb += 16) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { As[ar][ac + t] = ra[t]; Bs[bk][bcol + t] = rb[t]; }
         __syncthreads();
+        if (kb + 16 < NG) {
+            const double* ag = Ap + (size_t)(br + ar) * NG + kb + 16 + ac;
+            const double* bg = Bp + (size_t)(kb + 16 + bk) * NG + bc + bcol;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { ra[t] = ag[t]; rb[t] = bg[t]; }
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int kq = s * 4 + (lane >> 4);

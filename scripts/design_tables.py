@@ -79,6 +79,17 @@ if sw and "sweep" in sw:
             t += f"; `SQ_INSTS_VALU_MFMA_MOPS_F64` {g['counters_mean_per_launch'].get('SQ_INSTS_VALU_MFMA_MOPS_F64', 0):.0f} per launch, MFMA busy {g['derived'].get('mfma_busy_frac', 0):.2f} of the kernel's cycles"
         t += ")"
     extra.append(t + ".")
+k5 = line(os.path.join(P, "sweep_build_k512.json"))
+if k5:
+    st = stats_avg("sweep_build_k512", "sweep_gemm<1>")
+    g = json.load(open(os.path.join(P, "pmc_sweep_gemm_k512.json"))) if os.path.exists(os.path.join(P, "pmc_sweep_gemm_k512.json")) else None
+    t = f"The same build for {k5['n_sets']} sets (`scripts/sweep_build_probe.py`, a grid that fills the chip): {k5['build_ms']:.2f} ms in all"
+    if st:
+        fl = 2.0 * 128 ** 3 * k5["n_sets"]
+        t += f"; `sweep_gemm` {st[0]:.1f} µs per launch = **{fl / (st[0] * 1e-6) / 1e12:.1f} TFLOP/s, {fl / (st[0] * 1e-6) / 1e12 / 78.6:.2f} of the FP64 matrix peak**"
+    if g:
+        t += f", MFMA busy {g['derived'].get('mfma_busy_frac', 0):.2f} of the kernel's cycles (`SQ_VALU_MFMA_BUSY_CYCLES`)"
+    extra.append(t + f"; worst table error of three sampled sets against the long-double host build {k5['worst_rel_table_error_of_3_sets']:.1e}.")
 vp = os.path.join(P, "valu_peak.json")
 if os.path.exists(vp):
     try:

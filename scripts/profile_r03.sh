@@ -7,8 +7,11 @@
 # usage: scripts/profile_r03.sh [leg ...]        default: every leg bench.py reports
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=$R/gpurun_out/profiles_r03; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+ALL=0; [ $# -eq 0 ] && ALL=1
+ONLY_BUILD=0; [[ "$*" == "sweep_build" ]] && { ONLY_BUILD=1; set -- none; }      # `profile_r03.sh sweep_build`: only the sweep-build block at the end
 LEGS=${@:-headline shard_b8192 shard_b16384 shard_b32768 config1_b1024 sweep_k64_b65536 config3_walk_C150 config3_walk_C150:f32 config4_mc_C200 config4_mc_C200:f32}
 for spec in $LEGS; do
+  [[ $spec == none ]] && continue
   leg=${spec%%:*}; dt=f64; [[ $spec == *:* ]] && dt=${spec##*:}
   case $leg in
     headline)      key=headline_b65536; kern='ismpc_tick_quad<'; batch=65536; steps=40 ;;
@@ -48,8 +51,19 @@ for spec in $LEGS; do
   rm -rf $OUT/tmp_$key/*/*/*agent_info.csv
 done
 
+# the sweep's table build at a size that fills the chip (512 sets): kernel stats + the MFMA counters of sweep_gemm
+if [ $ALL -eq 1 ] || [ $ONLY_BUILD -eq 1 ]; then
+  SB="python3 $R/scripts/sweep_build_probe.py 512"
+  rm -rf $OUT/tmp_sweep_build; mkdir -p $OUT/tmp_sweep_build
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp_sweep_build/stats -- $SB > $OUT/sweep_build_k512.json 2> $OUT/tmp_sweep_build/stats.err || { tail -5 $OUT/tmp_sweep_build/stats.err; exit 1; }
+  cp $(find $OUT/tmp_sweep_build/stats -name "*kernel_stats.csv" | head -1) $OUT/sweep_build_k512_kernel_stats.csv
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU --output-format csv -d $OUT/tmp_sweep_build/mfma -- $SB > /dev/null 2> $OUT/tmp_sweep_build/mfma.err || { tail -5 $OUT/tmp_sweep_build/mfma.err; exit 1; }
+  python3 $R/scripts/pmc_summary.py $OUT/tmp_sweep_build "sweep_gemm" $OUT/pmc_sweep_gemm_k512.json sets=512 NG=128 > /dev/null
+  grep -E "mfma_busy_frac|mfma_f64_flops" $OUT/pmc_sweep_gemm_k512.json | tr -d '\n'; echo; grep sweep_gemm $OUT/sweep_build_k512_kernel_stats.csv | cut -c1-40,200-260
+  rm -rf $OUT/tmp_sweep_build/*/*/*agent_info.csv
+fi
 # the complete line (every leg, host-path extras, cpu_baseline) and the box's VALU rates, when the whole set was regenerated
-if [ $# -eq 0 ]; then
+if [ $ALL -eq 1 ]; then
   export ISMPC_PROFILES_DIR=$OUT
   timeout -k 10 900 python3 $R/bench.py > $OUT/bench_full_line.json 2> $OUT/bench_full.err || { tail -5 $OUT/bench_full.err; exit 1; }
   [ -x $R/build/valu_peak ] && $R/build/valu_peak > $OUT/valu_peak.json
