@@ -615,7 +615,7 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
         # data preparation, not the timed path: a nominal closed loop spreads the gait phases.  It runs on a second handle
         # with the OTHER arithmetic type, so that its 60 cheap launches carry another kernel name and a rocprofv3 --stats
         # summary of this process averages only the timed launches under the leg's kernel
-        # (an fp32 handle follows every launch with a one-workgroup fp64 launch for the QPs it could not solve: switched off on
+        # (an fp32 handle follows every launch with a small fp64 launch (up to 64 workgroups) for the QPs it could not solve: switched off on
         # the preparation handle, or those would carry the fp64 leg's kernel name)
         saved = os.environ.get("ISMPC_A_F32_RESOLVE"); os.environ["ISMPC_A_F32_RESOLVE"] = "0"
         prep = FA.GaitGenerator(FA.default_params(0, C=Cn, P=Pn, F=Fn), plans[0], device=R.local_rank,

@@ -131,7 +131,7 @@ int ismpc_a_rollout_device(ismpc_a_handle* h, int batch, ismpc_a_state* state_de
  * LIP update of the state (quad_walk_no_plots.m:297-322) is fp64; with fp32 = 1 the active-set iterations, the small
  * linear systems and the returned u0 / f0 carry fp32 rounding (relative CoM error of a tick stays below 1e-6: a tick moves
  * the CoM by B_upd u0 with |B_upd| ~ 1e-6..1e-3).  A QP whose working set pins (nearly) the whole horizon is beyond the
- * fp32 block solve; it is solved by the fp64 instantiation in a one-workgroup launch that follows every fp32 launch on the
+ * fp32 block solve; it is solved by the fp64 instantiation in a small launch (up to 64 workgroups) that follows every fp32 launch on the
  * same stream (about one QP in 30 000 at pushes 1.5x the bench's).  Needs 3 <= F <= 6. */
 int ismpc_a_set_precision(ismpc_a_handle* h, int fp32);
 

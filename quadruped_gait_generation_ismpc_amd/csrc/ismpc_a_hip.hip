@@ -1095,7 +1095,7 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
             wrc = go(WL);
             if (wrc == 0 && resolve) {
                 // the QPs the fp32 launch handed over (block-solve check failed: a horizon pinned end to end), solved by the fp64
-                // instantiation: one workgroup, usually nothing to do
+                // instantiation: usually nothing to do
                 ismpc_a::WaveLaunch W2 = WL;
                 W2.precision = 0; W2.work_counter = h->work_counter + 1; W2.order = h->defer_list; W2.count_ptr = h->work_counter + 2;
                 W2.order_is_qp = 1; W2.defer_list = nullptr; W2.defer_count = nullptr; W2.static_q = 0; W2.claim_chunk = 1;

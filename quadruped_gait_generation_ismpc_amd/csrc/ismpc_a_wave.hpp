@@ -959,7 +959,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #endif
                             // fp32: a working set that pins (nearly) the whole horizon is beyond the block solve's accuracy, and the
                             // cold start that follows is 100-150 one-row steps -- one such QP in 30 000 makes its launch 2-3x longer.
-                            // It goes to the fp64 instantiation instead (a one-workgroup launch right behind this one)
+                            // It goes to the fp64 instantiation instead (a small launch right behind this one)
                             if (sizeof(R) == 4 && defer_list != nullptr) defer_qp = true;
                             cold = true; break;
                         }

@@ -2,7 +2,7 @@
 """Register / scratch / LDS budget of every gfx950 kernel in the library, from hipcc's own resource analysis
 (-Rpass-analysis=kernel-resource-usage; the same numbers llvm-readelf --notes shows in the code object's metadata:
 .vgpr_count, .vgpr_spill_count, .private_segment_fixed_size, .group_segment_fixed_size).  No GPU needed.
-usage: python scripts/kernel_resources.py [--md profiles/r02/kernel_resources.md] [substring ...]"""
+usage: python scripts/kernel_resources.py [--md profiles/r03/kernel_resources.md] [substring ...]"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "quadruped_gait_generation_ismpc_amd", "csrc")

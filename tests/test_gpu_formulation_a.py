@@ -694,7 +694,7 @@ def test_heavily_pushed_flags_match_reference_solver(FA, precision):
 def test_fp32_pinned_horizon_is_resolved_in_fp64(FA, monkeypatch):
     """A working set that pins (nearly) the whole horizon is beyond the fp32 block solve: its check fails.  Such a QP is not
     started cold (100-150 one-row steps: one of them makes a launch of 16 384 instances 2-3x longer) but handed to the fp64
-    instantiation in a one-workgroup launch behind the fp32 one.  Workload: the bench generator at 1.5x its push, stream 1
+    instantiation in a small launch (up to 64 workgroups) behind the fp32 one.  Workload: the bench generator at 1.5x its push, stream 1
     (holds one such QP in 32 768); checked: same flags and next state as the fp64 solve, and the worst QP stays short."""
     import torch
     from quadruped_gait_generation_ismpc_amd import workload
