@@ -316,11 +316,17 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     const DevA& c = *cp;                                   // handle constants, read from memory where they are used (by value they would
     constexpr int m = 2 * F + 1;                           // sit in 70 scalar registers for the whole persistent loop)
     __shared__ WaveLds<R, F> lds_all[WG / 64];
-    __shared__ R a_s[WG], pa_s[WG + 1];                    // stability row and its prefix sums: same for every QP of the handle
+    __shared__ R a_s[PI ? 1 : WG], pa_s[PI ? 1 : WG + 1];  // stability row and its prefix sums: same for every QP of the handle
     __shared__ R a_pi[PI ? WG / 64 : 1][PI ? WG : 1], pa_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1];   // ... or one per wavefront
     // the same prefix sums and those of a^2 in fp64, whatever the precision of the solve: the two places where the stability row
     // is (nearly) in the span of the active ZMP rows are evaluated from them without cancellation (see gap_terms below)
     __shared__ R rinv[WG + 1];                              // 1 / g for the index gaps g = 1 .. C between active rows (a read instead of a division)
+    // G = V'K^-1 V / dt^2 from the Gram sums of a block solve: entry e = (i, j) of the m x m matrix is scale(e) x (at most four signed
+    // entries of L.th).  Which ones is a property of (e, F) alone: tabulated once per workgroup -- evaluated in place it was ~110 VALU
+    // instructions and four dependent LDS round trips per entry, on every block solve.
+    __shared__ unsigned int gdesc[m * m];                   // four bytes per entry: L.th index (bits 0-5) | sign as a 2-bit integer (6-7; 0: unused)
+    __shared__ unsigned char gkind[m * m];                  // scale: 0 = 1, 1 = 1 / sqrt(Qf), 2 = 1 / Qf  (5 bytes per entry in all: the
+                                                            // per-instance fp32 shape sits 100 bytes under the LDS that four workgroups per CU allow)
     __shared__ double pad_s[PI ? 1 : WG + 1], pa2d_s[PI ? 1 : WG + 1];
     __shared__ double pad_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1], pa2d_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1];
     // `lane` is re-declared opaque (LANE_FRESH) at the head of every solver phase: comparisons against it (lane == k, lane < m, the
@@ -336,8 +342,35 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     const bool klane = lane >= 1 && lane <= F;            // lane r owns kinematic row r (and f_r)
     for (int k = threadIdx.x; k <= WG; k += WG) rinv[k] = k > 0 ? (R)(1.0 / (double)k) : R(0);
     if (threadIdx.x == 0) rinv[WG] = (R)(1.0 / (double)WG);
+    for (int e = threadIdx.x; e < m * m; e += WG) {
+        constexpr int NT_ = F * (F + 1) / 2;
+        // Phi(e): e < F -> +col e+1 ; e > F -> -col (e-F) + col (e-F-1) [if >= 1]; Theta(r, q) (1-based, symmetric) sits at TH(r, q) of L.th
+        auto TH = [](int r, int q) { const int lo_ = r < q ? r : q, hi_ = r < q ? q : r; return (lo_ - 1) * F - ((lo_ - 1) * (lo_ - 2)) / 2 + (hi_ - lo_); };
+        const int i_ = e / m, j_ = e - i_ * m;
+        const int ra = i_ < F ? i_ + 1 : i_ - F, rb = j_ < F ? j_ + 1 : j_ - F;     // leading column of Phi(e)
+        const int sa = i_ < F ? 1 : -1, sb = j_ < F ? 1 : -1;
+        const bool a2 = i_ > F && ra >= 2, b2 = j_ > F && rb >= 2;                   // second term: +col (r-1)
+        int id0 = 0, id1 = 0, id2 = 0, id3 = 0, cf0 = 0, cf1 = 0, cf2 = 0, cf3 = 0, kd;      // scalars, not arrays: a dynamically indexed
+        if (i_ == F && j_ == F) { id0 = NT_ + 2 * F; cf0 = 1; kd = 0; }                     // private array would be promoted to 8 KB of LDS
+        else if (i_ == F || j_ == F) {
+            const int r_ = (i_ == F) ? rb : ra, s1 = (i_ == F) ? sb : sa; const bool t2 = (i_ == F) ? b2 : a2;
+            id0 = NT_ + r_ - 1; cf0 = s1;
+            if (t2) { id1 = NT_ + r_ - 2; cf1 = 1; }
+            kd = 1;
+        } else {
+            id0 = TH(ra, rb); cf0 = sa * sb;
+            if (a2) { id1 = TH(ra - 1, rb); cf1 = sb; }
+            if (b2) { id2 = TH(ra, rb - 1); cf2 = sa; }
+            if (a2 && b2) { id3 = TH(ra - 1, rb - 1); cf3 = 1; }
+            kd = 2;
+        }
+        static_assert(F * (F + 1) / 2 + 2 * F + 2 <= 64, "L.th index fits six bits");
+        gdesc[e] = (unsigned)(id0 | ((cf0 & 3) << 6)) | ((unsigned)(id1 | ((cf1 & 3) << 6)) << 8) | ((unsigned)(id2 | ((cf2 & 3) << 6)) << 16) |
+                   ((unsigned)(id3 | ((cf3 & 3) << 6)) << 24);
+        gkind[e] = (unsigned char)kd;
+    }
     if (!PI) {
-        for (int k = threadIdx.x; k <= C; k += WG) { pa_s[k] = (R)c.PA[k]; pad_s[k] = c.PA[k]; pa2d_s[k] = c.PA2[k]; if (k < C) a_s[k] = (R)c.a[k]; }
+        for (int k = threadIdx.x; k <= C; k += WG) { pa_s[PI ? 0 : k] = (R)c.PA[k]; pad_s[k] = c.PA[k]; pa2d_s[k] = c.PA2[k]; if (k < C) a_s[PI ? 0 : k] = (R)c.a[k]; }
     }
     __syncthreads();
     const R* ap = PI ? a_pi[PI ? wv : 0] : a_s;
@@ -698,31 +731,14 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     }
                     WAVE_LDS_SYNC();
                     PH(6);                                 // 6: block solve: fold over the wavefront
-                    // Phi(e): e < F -> +col e+1 ; e > F -> -col (e-F) + col (e-F-1) [if >= 1] ; all scaled by 1/sqrt(Qf)
-                    auto TH = [&](int r, int q) -> R {                       // Theta(r, q), 1-based, symmetric
-                        const int lo_ = min(r, q), hi_ = max(r, q);
-                        return L.th[(lo_ - 1) * F - ((lo_ - 1) * (lo_ - 2)) / 2 + (hi_ - lo_)];
-                    };
+                    // G from the Gram sums through the per-workgroup table (gidx / gcoef / gkind, built at kernel start)
                     for (int e = lane; e < m * m; e += 64) {
-                        const int i_ = e / m, j_ = e - i_ * m;
-                        const int ra = i_ < F ? i_ + 1 : i_ - F, rb = j_ < F ? j_ + 1 : j_ - F;     // leading column of Phi(e)
-                        const R sa = i_ < F ? R(1) : R(-1), sb = j_ < F ? R(1) : R(-1);
-                        const bool a2 = i_ > F && ra >= 2, b2 = j_ > F && rb >= 2;                   // second term: +col (r-1)
-                        R val;
-                        if (i_ == F && j_ == F) val = L.th[NT + 2 * F];
-                        else if (i_ == F || j_ == F) {
-                            const int r_ = (i_ == F) ? rb : ra; const R s1 = (i_ == F) ? sb : sa; const bool t2 = (i_ == F) ? b2 : a2;
-                            val = s1 * L.th[NT + r_ - 1];
-                            if (t2) val += L.th[NT + r_ - 2];
-                            val *= isq;
-                        } else {
-                            val = sa * sb * TH(ra, rb);
-                            if (a2) val += sb * TH(ra - 1, rb);
-                            if (b2) val += sa * TH(ra, rb - 1);
-                            if (a2 && b2) val += TH(ra - 1, rb - 1);
-                            val *= isq * isq;
-                        }
-                        L.G[e] = val;
+                        const unsigned dsc = gdesc[e];
+                        R val = R(0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) val += (R)((int)(dsc << (24 - 8 * t)) >> 30) * L.th[(dsc >> (8 * t)) & 63u];
+                        const int kd = gkind[e];
+                        L.G[e] = val * (kd == 0 ? R(1) : (kd == 1 ? isq : isq * isq));
                     }
                     if (lane < m) {
                         R gv;
