@@ -325,8 +325,11 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     // entries of L.th).  Which ones is a property of (e, F) alone: tabulated once per workgroup -- evaluated in place it was ~110 VALU
     // instructions and four dependent LDS round trips per entry, on every block solve.
     __shared__ unsigned int gdesc[m * m];                   // four bytes per entry: L.th index (bits 0-5) | sign as a 2-bit integer (6-7; 0: unused)
-    __shared__ unsigned char gkind[m * m];                  // scale: 0 = 1, 1 = 1 / sqrt(Qf), 2 = 1 / Qf  (5 bytes per entry in all: the
-                                                            // per-instance fp32 shape sits 100 bytes under the LDS that four workgroups per CU allow)
+    __shared__ unsigned char gkind[m * m];                  // bits 0-1 scale: 0 = 1, 1 = 1 / sqrt(Qf), 2 = 1 / Qf; bits 2-4: the CONSTANT part of the
+                                                            // small system at this entry as a 3-bit integer (+1 on the footstep diagonal, -S_xx on the
+                                                            // kinematic block: -2 / -1 on its diagonal, +1 beside it) -- L.G holds G plus that constant,
+                                                            // so the solve reads its matrix instead of re-deriving the pattern per entry  (5 bytes per
+                                                            // entry in all: the per-instance fp32 shape sits 80 bytes under the LDS of four workgroups per CU)
     __shared__ double pad_s[PI ? 1 : WG + 1], pa2d_s[PI ? 1 : WG + 1];
     __shared__ double pad_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1], pa2d_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1];
     // `lane` is re-declared opaque (LANE_FRESH) at the head of every solver phase: comparisons against it (lane == k, lane < m, the
@@ -335,6 +338,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     // state against one v_cmp to recompute it)
     int lane = threadIdx.x & 63;
 #define LANE_FRESH() asm volatile("" : "+v"(lane))
+#define G_CONST(kd_) ((R)(((int)((unsigned)(kd_) << 27)) >> 29))      /* bits 2-4 of gkind, sign-extended */
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds<R, F>& L = lds_all[wv];
     const int C = c.C, P = c.P;
@@ -367,7 +371,10 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         static_assert(F * (F + 1) / 2 + 2 * F + 2 <= 64, "L.th index fits six bits");
         gdesc[e] = (unsigned)(id0 | ((cf0 & 3) << 6)) | ((unsigned)(id1 | ((cf1 & 3) << 6)) << 8) | ((unsigned)(id2 | ((cf2 & 3) << 6)) << 16) |
                    ((unsigned)(id3 | ((cf3 & 3) << 6)) << 24);
-        gkind[e] = (unsigned char)kd;
+        int sc = 0;                                          // [[I + G11, G1x], [Gx1, Gxx - Sxx]]: the identity and -Sxx
+        if (i_ < F && j_ == i_) sc = 1;
+        if (i_ > F && j_ > F) { const int r1 = i_ - F, r2 = j_ - F; sc = (r1 == r2) ? (r1 >= 2 ? -2 : -1) : ((r1 - r2 == 1 || r2 - r1 == 1) ? 1 : 0); }
+        gkind[e] = (unsigned char)(kd | ((sc & 7) << 2));
     }
     if (!PI) {
         for (int k = threadIdx.x; k <= C; k += WG) { pa_s[PI ? 0 : k] = (R)c.PA[k]; pad_s[k] = c.PA[k]; pa2d_s[k] = c.PA2[k]; if (k < C) a_s[PI ? 0 : k] = (R)c.a[k]; }
@@ -550,7 +557,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #pragma unroll
             for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; u[k] = (i <= C) ? t0 * ap[i - 1] : R(0); }
             muE = t0;
-            for (int e = lane; e < m * m; e += 64) L.G[e] = R(0);
+            for (int e = lane; e < m * m; e += 64) L.G[e] = G_CONST(gkind[e]);     // no active ZMP row: G = 0, the constant part stays
             if (lane <= F + 1) L.pf[lane] = fr;
             WAVE_LDS_SYNC();
 
@@ -612,13 +619,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 R Tr[m + 1];
 #pragma unroll
                 for (int jj = 0; jj < m; ++jj) {
-                    R val = L.G[i * m + jj];
-                    if (jj < F && i == jj) val += R(1);
+                    R val = L.G[i * m + jj];                                        // G plus the constant part (identity, -Sxx): see gkind
                     if (jj == F && i == F) val = -Dee;                              // G_EE - a'a without the cancellation
-                    if (jj > F && i > F) {
-                        const int r1 = i - F, r2 = jj - F;
-                        val -= (r1 == r2) ? (r1 >= 2 ? R(2) : R(1)) : ((r1 - r2 == 1 || r2 - r1 == 1) ? R(-1) : R(0));
-                    }
                     const bool jpin = jj > F && !((kmask >> (jj - F)) & 1ull);
                     if (ipin || jpin) val = (i == jj) ? R(-1) : R(0);
                     Tr[jj] = val;
@@ -738,7 +740,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #pragma unroll
                         for (int t = 0; t < 4; ++t) val += (R)((int)(dsc << (24 - 8 * t)) >> 30) * L.th[(dsc >> (8 * t)) & 63u];
                         const int kd = gkind[e];
-                        L.G[e] = val * (kd == 0 ? R(1) : (kd == 1 ? isq : isq * isq));
+                        L.G[e] = val * ((kd & 3) == 0 ? R(1) : ((kd & 3) == 1 ? isq : isq * isq)) + G_CONST(kd);
                     }
                     if (lane < m) {
                         R gv;
@@ -1029,7 +1031,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     for (int k = 0; k < RL; ++k) { const int i = lane * RL + k + 1; PN_RESET_(k); mu[k] = R(0); u[k] = (i <= C) ? t0 * ap[i - 1] : R(0); }
                     if (klane) fr = L.pf[lane];
                     muE = t0; qz = 0; Dd = pa2d[C]; Dee = (R)Dd;
-                    for (int e = lane; e < m * m; e += 64) L.G[e] = R(0);
+                    for (int e = lane; e < m * m; e += 64) L.G[e] = G_CONST(gkind[e]);
                     WAVE_LDS_SYNC();
                     // a previous-tick guess that the passes could not repair: solve this QP the way a one-shot tick is solved
                     // (a closed loop's tick is as long as its slowest QP, and a cold Goldfarb-Idnani solve is 50-100 steps)
@@ -1135,6 +1137,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         R h_e = sg * vint;
 #pragma unroll
                         for (int r = 0; r < F; ++r) h_e += L.G[lane * m + r] * L.mt[r];
+                        if (lane < F) h_e -= L.mt[lane];                                // (L.G carries the identity of the footstep block: G alone is meant here)
                         L.hx[lane] = h_e - dx_e;
                     }
                     WAVE_LDS_SYNC();
