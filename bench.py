@@ -429,7 +429,7 @@ def kernel_name_b(N, B, cus):
     lpi = _lpi(B)
     if one_launch(N, B, cus) and os.environ.get("ISMPC_Z_FALLBACK") != "0":
         return "ismpc_tick_quad_inline<%d, %d, %d>" % (_quad_r(N, lpi), lpi, (N + 63) // 64)
-    return "ismpc_tick_quad<%d, %d>" % (_quad_r(N, lpi), lpi)
+    return "ismpc_tick_quad<%d, %d, false>" % (_quad_r(N, lpi), lpi)
 
 
 def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
