@@ -61,7 +61,8 @@ extern "C" {
 #define ISMPC_ST_TICK_SKIPPED  32  /* controlIter % (int)(100 dt) != 0 (MPCSolver.cpp:214):
                                       state passed through -- not an error                  */
 #define ISMPC_ST_Z_NAN         64  /* NaN guard fired (MPCSolver.cpp:277-278)               */
-#define ISMPC_ST_Z_FAILED      128 /* vertical fallback: more than 16 active rows, or infeasible */
+#define ISMPC_ST_Z_FAILED      128 /* vertical fallback: iteration limit hit or infeasible (the working set may hold
+                                      every row of the horizon); never fed back in closed loops */
 
 /* ---- parameters: parameters.cpp:9-45 and MPCSolver.cpp:253-255 ---------- */
 typedef struct ismpc_params {
