@@ -96,3 +96,22 @@ def test_formulation_a_abi(built_libs):
     pw, ow = FA.default_params(FA.WALK), A.params(A.WALK)
     for name, _ in FA.ParamsA._fields_:
         assert getattr(pw, name) == getattr(ow, name), name
+
+
+def test_sweep_validation_and_no_cpu_fallback(built_libs):
+    """ismpc_create_sweep: sets that disagree on the shape of the problem are refused before anything touches a device; without a GPU
+    a valid sweep fails like ismpc_create does (no CPU table build in disguise)."""
+    import torch
+    import quadruped_gait_generation_ismpc_amd as q
+    a, b = q.default_params(N=100), q.default_params(N=50)
+    with pytest.raises(q.IsmpcError) as e:
+        q.MPCSolver.sweep(q.reference_plan(params=a), [a, b])
+    assert e.value.code == -1 and "share N" in str(e.value)
+    c = q.default_params(N=100); c.mass = -1.0
+    with pytest.raises(q.IsmpcError) as e:
+        q.MPCSolver.sweep(q.reference_plan(params=a), [a, c])
+    assert e.value.code == -1
+    if not torch.cuda.is_available():
+        with pytest.raises(q.IsmpcError) as e:
+            q.MPCSolver.sweep(q.reference_plan(params=a), [a, q.default_params(N=100)])
+        assert e.value.code == -2 and "no CPU fallback" in str(e.value)
