@@ -308,6 +308,30 @@ __global__ __launch_bounds__(256) void sweep_tail(const double* __restrict__ par
     tailx[(size_t)set * s_tail + idx] = sx; taily[(size_t)set * s_tail + idx] = sy;
 }
 
+// ---- did the build work?  Per set: max |I - H X| over the N x N block (a Hessian that is not positive definite, or one so badly
+// conditioned that the iteration count ran out, leaves a residual of order one or NaN) and finiteness of the affine tables.
+__global__ __launch_bounds__(256) void sweep_check(const double* __restrict__ H, const double* __restrict__ X, size_t smat, const double* __restrict__ vtab, size_t s_vtab,
+                                                   int N, int NG, double* __restrict__ resid)
+{
+    __shared__ double red[256];
+    const int set = blockIdx.x, tid = threadIdx.x;
+    const double* Hs = H + (size_t)set * smat; const double* Xs = X + (size_t)set * smat;
+    double worst = 0.0;
+    for (int e = tid; e < N * N; e += blockDim.x) {
+        const int i = e / N, j = e - i * N;
+        double acc = (i == j) ? -1.0 : 0.0;
+        for (int k = 0; k < N; ++k) acc = fma(Hs[(size_t)i * NG + k], Xs[(size_t)k * NG + j], acc);
+        const double a = fabs(acc);
+        worst = (a > worst || a != a) ? (a != a ? INFINITY : a) : worst;
+    }
+    const double* vt = vtab + (size_t)set * s_vtab;
+    for (size_t e = tid; e < s_vtab; e += blockDim.x) { const double v = vt[e]; if (!(fabs(v) < INFINITY)) worst = INFINITY; }
+    red[tid] = worst;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmax(red[tid], red[tid + o]); __syncthreads(); }
+    if (tid == 0) resid[set] = red[0];
+}
+
 #define SW_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return ISMPC_E_NO_DEVICE; } } while (0)
 
 int dalloc(double** p, size_t n, std::vector<void*>& allocs, std::string& err)
@@ -396,8 +420,26 @@ int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double*
     hipLaunchKernelGGL(sweep_tail, dim3((t0.nmid + 255) / 256, K), dim3(256), 0, s, (const double*)o.par, midx_dev, midy_dev, t0.nmid, o.tailx, o.taily, o.s_tail, N, dt);
     SW_TRY(hipGetLastError());
     SW_TRY(hipEventRecord(e1, s));
+    // the build is checked, not trusted: |I - H X| of every set and finite tables
+    double* resid_dev = nullptr;
+    if ((rc = dalloc(&resid_dev, (size_t)K, allocs, err))) return rc;
+    hipLaunchKernelGGL(sweep_check, dim3(K), dim3(256), 0, s, (const double*)o.H, (const double*)o.X0, o.s_mat, (const double*)o.vtab, o.s_vtab, N, NG, resid_dev);
+    std::vector<double> resid((size_t)K);
+    SW_TRY(hipMemcpyAsync(resid.data(), resid_dev, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, s));
     SW_TRY(hipStreamSynchronize(s));
     SW_TRY(hipEventElapsedTime(&o.build_ms, e0, e1));
+    o.max_residual = 0.0;
+    for (int k = 0; k < K; ++k) {
+        // a converged iterate leaves cond(H) x (relative error of X ~ cond eps): far below 1e-3 for any set the affine tables make sense for; an
+        // iteration that ran out of budget, or a Hessian that is not positive definite, leaves O(1) or NaN.  (Accuracy is cond(H) eps, as for
+        // any inverse in fp64: ismpc_sweep_verify_tables measures it against the long-double host build.)
+        if (!(resid[k] <= 1e-3)) {
+            err = "parameter set " + std::to_string(k) + ": the vertical Hessian could not be inverted (not positive definite, or conditioned beyond the "
+                  "Newton-Schulz iteration budget): residual |I - H X| = " + std::to_string(resid[k]);
+            return ISMPC_E_NUMERIC;
+        }
+        o.max_residual = std::max(o.max_residual, resid[k]);
+    }
     o.newton_iters = iters; o.gemm_launches = launches;
     return ISMPC_OK;
 }

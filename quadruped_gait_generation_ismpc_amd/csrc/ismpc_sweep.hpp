@@ -32,6 +32,7 @@ struct SweepSlabs {                 // one device slab per table kind, set k at 
     double* par = nullptr;          // K x 8: mass, q_p, q_u, q_v, h_des, eta, 1 / bound(|H|_inf), g
     int newton_iters = 0, gemm_launches = 0;
     float build_ms = 0.f;
+    double max_residual = 0.0;      // max over the sets of |I - H X| (checked by sweep_build: a set above 1e-3 fails the build)
 };
 
 // Builds every per-set table on `stream` (synchronises before returning).  `t0` = host tables of set 0 (plan, patterns, structure).

@@ -174,3 +174,22 @@ def test_sweep_in_kernel_rollout_is_bitwise_the_per_tick_loop(q, monkeypatch):
     assert ((out["status"][:, tight] & q.ST_Z_INEQ_ACTIVE) != 0).any(axis=0).all()       # those instances went through the resume launch
     assert ((out["status"] & q.ST_Z_FAILED) == 0).all()
     a.close(); b.close()
+
+
+def test_sweep_build_is_checked_not_trusted(q):
+    """Every set's inverse is verified on the device (|I - H X| and finite tables): a set whose Hessian is conditioned beyond the iteration
+    budget fails ismpc_create_sweep with ISMPC_E_NUMERIC and names the set; a stiff but tractable one (cond ~ 1e7) builds and solves."""
+    p0 = q.default_params(N=100)
+    bad = q.default_params(N=100); bad.q_u = 1e-40
+    with pytest.raises(q.IsmpcError) as e:
+        q.MPCSolver.sweep(q.reference_plan(params=p0), [p0, bad])
+    assert e.value.code == -4 and "parameter set 1" in str(e.value)
+    stiff = q.default_params(N=100); stiff.q_p = 1e8; stiff.q_u = 1e-4
+    s = q.MPCSolver.sweep(q.reference_plan(params=p0), [p0, stiff])
+    err = s.sweep_verify_tables(1)
+    assert err["Hinv"] <= 1e-8 and max(err.values()) <= 1e-6, err          # cond(H) eps: nine digits at cond 3e7
+    from quadruped_gait_generation_ismpc_amd import workload
+    tin = workload.make_batch(100, 256, seed=2); tin["reserved"] = 1
+    out = s.solve_batch(tin)
+    assert ((out["status"] & q.ST_BAD_INDEX) == 0).all() and np.isfinite(out["com_pos"]).all()
+    s.close()
