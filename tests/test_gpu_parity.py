@@ -436,3 +436,33 @@ def test_in_kernel_rollout_is_bitwise_the_per_tick_loop(q, O, N, ticks, over, la
     sc = q.to_device(recs)
     a.rollout_torch(sc, 0, ticks, want_traj=False); torch.cuda.synchronize()
     assert torch.equal(sc, sa)
+
+
+def test_handle_scratch_growth_across_streams_and_independent_handles(q):
+    """A handle's per-launch scratch outlives the call that allocated it: growing it on another stream than the previous launch's drains that
+    stream first (round 2 freed it while kernels of the other stream could still use it).  A long closed loop on stream A, then at once a
+    larger batch on stream B through the SAME handle, with the inequality fallback active in both; and two handles on two streams at once."""
+    import torch
+    from quadruped_gait_generation_ismpc_amd import workload
+    p = q.default_params(N=100, z_ineq_hi=4.6)
+    plan = q.reference_plan(params=p)
+    h1, h2 = q.MPCSolver(plan, params=p), q.MPCSolver(plan, params=p)
+    small, big = workload.make_batch(100, 3000, seed=31), workload.make_batch(100, 40000, seed=32)
+    ref_small, ref_big = h2.solve_batch(small), h2.solve_batch(big)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    d_small, d_big = q.to_device(small), q.to_device(big)
+    torch.cuda.synchronize()
+    outs = []
+    with torch.cuda.stream(sa):
+        for _ in range(200):
+            o_small = h1.solve_batch_torch(d_small)                       # 200 launches queued on stream A (scratch sized for 3 000)
+    with torch.cuda.stream(sb):
+        o_big = h1.solve_batch_torch(d_big)                               # growth to 40 000 on stream B while A may still be running
+        for _ in range(20):
+            outs.append(h2.solve_batch_torch(d_small))                    # another handle, concurrently
+    torch.cuda.synchronize()
+    assert q.from_device(o_small, q.TICK_OUT).tobytes() == ref_small.tobytes()
+    assert q.from_device(o_big, q.TICK_OUT).tobytes() == ref_big.tobytes()
+    assert q.from_device(outs[-1], q.TICK_OUT).tobytes() == ref_small.tobytes()
+    assert ((ref_big["status"] & q.ST_Z_INEQ_ACTIVE) != 0).sum() > 100
+    h1.close(); h2.close()
