@@ -785,3 +785,30 @@ def test_entry_points_run_on_the_handles_device_whatever_is_current(FA):
     st2 = q_to_dev(ref.initial_state(g.disp_C, batch=2)); feet2 = ref.feet_init_torch(g, fp0, batch=2)
     t2 = ref.rollout_feet_torch(st2, feet2, 30); torch.cuda.synchronize()
     assert torch.equal(t2, traj) and torch.equal(feet2, feet)
+
+
+def test_scratch_growth_across_streams(FA):
+    """As for Formulation B: the handle's copy of the previous state and the work lists grow inside an asynchronous entry point; when the
+    call's stream is not the previous call's, that stream is drained before the old block is released."""
+    import torch
+    from quadruped_gait_generation_ismpc_amd import workload
+    w = workload.make_batch_a("walk_C100", 20000, seed=3)
+    g = FA.default_gait(w["kind"], w["phi"], w["disp_A"]); _, ce = FA.plan(g)
+    p = FA.default_params(w["kind"], C=w["C"], P=w["P"], F=w["F"])
+    gen, ref = FA.GaitGenerator(p, ce, precision="f32"), FA.GaitGenerator(p, ce, precision="f32")
+    push = torch.from_numpy(w["push"].copy()).to("cuda:0")
+    r_small = q_from_dev(ref.tick_torch(q_to_dev(w["state"][:1500]), push[:1500].contiguous()), FA.OUT_A)
+    r_big = q_from_dev(ref.tick_torch(q_to_dev(w["state"]), push), FA.OUT_A)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    st_small = [q_to_dev(w["state"][:1500]) for _ in range(40)]; st_big = q_to_dev(w["state"]); ps = push[:1500].contiguous()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa):
+        for st in st_small:
+            o_small = gen.tick_torch(st, ps)
+    with torch.cuda.stream(sb):
+        o_big = gen.tick_torch(st_big, push)
+    torch.cuda.synchronize()
+    a, b = q_from_dev(o_small, FA.OUT_A), q_from_dev(o_big, FA.OUT_A)
+    for k in ("status", "u0", "f0", "vel_after", "com_before"):
+        assert np.array_equal(a[k], r_small[k]) and np.array_equal(b[k], r_big[k]), k
+    gen.close(); ref.close()
