@@ -593,14 +593,15 @@ __device__ __forceinline__ double sample_at(const double (&v)[R], int k)     // 
     for (int r = 1; r < R; ++r) if (slot == r) x = v[r];
     return readlane_dyn(x, owner);
 }
+// Folds the equality pattern into a row of (HSt, SHSt) or into a combination of such rows: p -= W_e ue_e, g -= (S W)_e ue_e with
+// ue_e = the UNPROJECTED vector at the e-th pinned sample (lane e holds it in `uel`); the pinned samples of p end up zero.
 template <int R>
-__device__ __forceinline__ void z_fetch(const DevConst& c, int row, int n0, int pat, int elo, int ne, double (&pc)[R], double (&gc)[R])
+__device__ __forceinline__ void z_project(const DevConst& c, int n0, int pat, int elo, int ne, double uel, double (&pc)[R], double (&gc)[R])
 {
     constexpr int NT = ismpc::Tables::NT;
-    loadR<R>(c.HSt + (size_t)row * NT + n0, pc); loadR<R>(c.SHSt + (size_t)row * NT + n0, gc);
-#pragma nounroll
+#pragma unroll 4
     for (int e = 0; e < ne; ++e) {
-        const double ue = c.HSt[(size_t)row * NT + elo + e];
+        const double ue = readlane_dyn(uel, e);
         double wv[R], sv[R];
         loadR<R>(c.Wt + ((size_t)pat * c.Fmax + e) * NT + n0, wv); loadR<R>(c.SW + ((size_t)pat * c.Fmax + e) * NT + n0, sv);
 #pragma unroll
@@ -609,7 +610,15 @@ __device__ __forceinline__ void z_fetch(const DevConst& c, int row, int n0, int 
 #pragma unroll
     for (int r = 0; r < R; ++r) { const int n = n0 + r; if (n >= elo && n < elo + ne) pc[r] = 0.0; }
 }
-// one wavefront's stores to its slot become visible to its other lanes (same CU: a wait for the stores is all it takes)
+template <int R>
+__device__ __forceinline__ void z_fetch(const DevConst& c, int lane, int row, int n0, int pat, int elo, int ne, double (&pc)[R], double (&gc)[R])
+{
+    constexpr int NT = ismpc::Tables::NT;
+    loadR<R>(c.HSt + (size_t)row * NT + n0, pc); loadR<R>(c.SHSt + (size_t)row * NT + n0, gc);
+    const double uel = (lane < ne) ? c.HSt[(size_t)row * NT + elo + lane] : 0.0;
+    z_project<R>(c, n0, pat, elo, ne, uel, pc, gc);
+}
+// one wavefront's stores to its working storage become visible to its other lanes (same CU: a wait for the stores is all it takes)
 #define Z_MEMSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // A slot of the pool: lane 0 takes the first free one starting at `hint`.  Holders always finish (bounded iteration
@@ -631,26 +640,38 @@ __device__ __forceinline__ void z_slot_release(const DevConst& c, int lane, int 
     if (lane == 0) atomicExch(&c.zbusy[slot], 0);
 }
 
+// Working storage of one solve: G^-1 (ld x ld), the per-entry vectors, g of the entering row by sample, the entries' rows.
+// Up to Z_LDS_Q entries it is the wavefront's own LDS window (Z_LDS_DOUBLES doubles, handed in by the kernel); a working set
+// that outgrows it moves to a slot of the pool in HBM (ld = zcap) and stays there.  The pointers are wave-uniform and generic.
+constexpr int Z_LDS_Q = 16;
+constexpr int Z_LDS_DOUBLES = Z_LDS_Q * Z_LDS_Q + 4 * Z_LDS_Q + ismpc::Tables::NT + Z_LDS_Q / 2;
+struct ZStore {
+    double *Ginv, *amu, *asg, *rv, *dv, *gs; int* arow; int ld;
+    __device__ __forceinline__ void bind(double* base, int ld_)
+    {
+        Ginv = base; ld = ld_; amu = base + (size_t)ld_ * ld_; asg = amu + ld_; rv = asg + ld_; dv = rv + ld_; gs = dv + ld_;
+        arow = reinterpret_cast<int*>(gs + ismpc::Tables::NT);
+    }
+};
+
 // returns the iteration count; updates u, su in place.  Entry j of the working set: row arow[j], bound sign asg[j] (+1 lower,
-// -1 upper), multiplier amu[j]; Ginv = G^-1 over the entries (ld = cap).
+// -1 upper), multiplier amu[j]; Ginv = G^-1 over the entries.
 template <int R>
-__device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double (&u)[R], double (&su)[R], int& status, int slot_hint)
+__device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double (&u)[R], double (&su)[R], int& status, int slot_hint, double* lds)
 {
     constexpr int NT = ismpc::Tables::NT;
     const int N = c.N, cap = c.zcap;
     int elo = 0, ne = 0;
     if (pat < c.npat) { elo = c.e_lo[pat]; ne = c.ne[pat]; }
     const double tol_lo = 1e-11 * fmax(1.0, fabs(c.z_lo)), tol_hi = 1e-11 * fmax(1.0, fabs(c.z_hi));
-    const int slot = z_slot_acquire(c, lane, slot_hint);
-    double* Ginv = c.zpool + (size_t)slot * c.zstride;
-    double* amu = Ginv + (size_t)cap * cap; double* asg = amu + cap; double* rv = asg + cap; double* dv = rv + cap;
-    double* gs = dv + cap;                                   // g of the entering row, by sample (NT)
-    int* arow = reinterpret_cast<int*>(gs + NT);
+    ZStore z; z.bind(lds, Z_LDS_Q);
+    int slot = -1;
     bool sact[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) sact[r] = false;
     int q = 0, its = 0;
     const int max_its = 8 * N + 64;
+    Z_MEMSYNC();                                             // whatever the caller kept in the window has been read
     for (;;) {
         // ---- most violated free row
         double best = 0.0; int code = 0;
@@ -670,8 +691,24 @@ __device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double
         const int row = code >> 1;
         const double sg = (code & 1) ? -1.0 : 1.0;
         if (q >= cap) { status |= ISMPC_ST_Z_FAILED; break; }             // cannot happen: entries are distinct rows, cap = N
+        if (q == z.ld && slot < 0) {
+            // ---- the working set outgrows the LDS window: everything moves to a pool slot
+            slot = z_slot_acquire(c, lane, slot_hint);
+            ZStore zp; zp.bind(c.zpool + (size_t)slot * c.zstride, cap);
+#pragma nounroll
+            for (int j = lane; j < q; j += 64) {
+#pragma nounroll
+                for (int k = 0; k < q; ++k) zp.Ginv[(size_t)k * cap + j] = z.Ginv[k * z.ld + j];
+                zp.amu[j] = z.amu[j]; zp.asg[j] = z.asg[j]; zp.arow[j] = z.arow[j];
+            }
+            z = zp;
+            Z_MEMSYNC();
+        }
+        double* const Ginv = z.Ginv; double* const amu = z.amu; double* const asg = z.asg; double* const rv = z.rv; double* const dv = z.dv;
+        double* const gs = z.gs; int* const arow = z.arow;
+        const size_t ld = (size_t)z.ld;
         double pc[R], gc[R];
-        z_fetch<R>(c, row, n0, pat, elo, ne, pc, gc);
+        z_fetch<R>(c, lane, row, n0, pat, elo, ne, pc, gc);
         const double npn = sample_at<R>(gc, row);
 #pragma unroll
         for (int r = 0; r < R; ++r) if (n0 + r < NT) gs[n0 + r] = gc[r];
@@ -690,8 +727,8 @@ __device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double
 #pragma nounroll
             for (int j = lane; j < q; j += 64) {
                 double acc = 0.0;
-#pragma nounroll
-                for (int k = 0; k < q; ++k) acc = fma(Ginv[(size_t)k * cap + j], dv[k], acc);       // column j = row j (symmetric)
+#pragma unroll 4
+                for (int k = 0; k < q; ++k) acc = fma(Ginv[(size_t)k * ld + j], dv[k], acc);        // column j = row j (symmetric)
                 rv[j] = acc; drl = fma(dv[j], acc, drl);
                 if (acc > 0.0) { const double tt = amu[j] / acc; if (tt < tcl) { tcl = tt; tl = j; } }
             }
@@ -702,18 +739,26 @@ __device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double
             const double t = fmin(t1, t2);
             if (!(t < INFINITY)) { fail = true; break; }
             if (t2 < INFINITY) {
-                // z = P (n+ - N r): columns of the entries, coefficient -r_j asg_j, plus the new one
-                double zu[R], zs[R];
+                // z = P (n+ - N r): the entries' rows of (HSt, SHSt) combined with coefficient -r_j asg_j (independent loads, four
+                // in flight), the equality pattern folded into the combination ONCE (it is linear), plus the new row
+                double zu[R], zs[R], vu[R], vs[R];
 #pragma unroll
-                for (int r = 0; r < R; ++r) { zu[r] = sg * pc[r]; zs[r] = sg * gc[r]; }
-#pragma nounroll
+                for (int r = 0; r < R; ++r) { vu[r] = 0.0; vs[r] = 0.0; }
+                double uel = 0.0;
+#pragma unroll 4
                 for (int j = 0; j < q; ++j) {
                     const double cf = -rv[j] * asg[j];
+                    const size_t rj = (size_t)arow[j] * NT;
                     double pj[R], gj[R];
-                    z_fetch<R>(c, arow[j], n0, pat, elo, ne, pj, gj);
+                    loadR<R>(c.HSt + rj + n0, pj); loadR<R>(c.SHSt + rj + n0, gj);
+                    const double uj = (lane < ne) ? c.HSt[rj + elo + lane] : 0.0;
+                    uel = fma(cf, uj, uel);
 #pragma unroll
-                    for (int r = 0; r < R; ++r) { zu[r] = fma(cf, pj[r], zu[r]); zs[r] = fma(cf, gj[r], zs[r]); }
+                    for (int r = 0; r < R; ++r) { vu[r] = fma(cf, pj[r], vu[r]); vs[r] = fma(cf, gj[r], vs[r]); }
                 }
+                if (q > 0) z_project<R>(c, n0, pat, elo, ne, uel, vu, vs);
+#pragma unroll
+                for (int r = 0; r < R; ++r) { zu[r] = fma(sg, pc[r], vu[r]); zs[r] = fma(sg, gc[r], vs[r]); }
 #pragma unroll
                 for (int r = 0; r < R; ++r) { u[r] = fma(t, zu[r], u[r]); su[r] = fma(t, zs[r], su[r]); }
             }
@@ -723,14 +768,14 @@ __device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double
             if (t2 < INFINITY && t == t2) {
                 // ---- the row enters: border update of G^-1
                 const double ig = 1.0 / gamma;
-    #pragma nounroll
-            for (int j = lane; j < q; j += 64) {
+#pragma nounroll
+                for (int j = lane; j < q; j += 64) {
                     const double rj = rv[j];
-    #pragma nounroll
-                for (int k = 0; k < q; ++k) Ginv[(size_t)k * cap + j] = fma(rv[k] * ig, rj, Ginv[(size_t)k * cap + j]);
-                    Ginv[(size_t)q * cap + j] = -rj * ig; Ginv[(size_t)j * cap + q] = -rj * ig;
+#pragma unroll 4
+                    for (int k = 0; k < q; ++k) Ginv[(size_t)k * ld + j] = fma(rv[k] * ig, rj, Ginv[(size_t)k * ld + j]);
+                    Ginv[(size_t)q * ld + j] = -rj * ig; Ginv[(size_t)j * ld + q] = -rj * ig;
                 }
-                if (lane == 0) { Ginv[(size_t)q * cap + q] = ig; arow[q] = row; asg[q] = sg; amu[q] = mu_p; }
+                if (lane == 0) { Ginv[(size_t)q * ld + q] = ig; arow[q] = row; asg[q] = sg; amu[q] = mu_p; }
 #pragma unroll
                 for (int r = 0; r < R; ++r) if (n0 + r == row) sact[r] = true;
                 ++q;
@@ -742,27 +787,27 @@ __device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double
             const int l = wave_allmin_i((tcl == t1) ? tl : (1 << 30));
             const int last = q - 1;
             const int drow = arow[l];
-            const double piv = Ginv[(size_t)l * cap + l];
+            const double piv = Ginv[(size_t)l * ld + l];
 #pragma nounroll
-            for (int j = lane; j < q; j += 64) rv[j] = Ginv[(size_t)l * cap + j];                   // column l
+            for (int j = lane; j < q; j += 64) rv[j] = Ginv[(size_t)l * ld + j];                    // column l
             Z_MEMSYNC();
 #pragma nounroll
             for (int j = lane; j < q; j += 64) {
                 if (j == l) continue;
                 const double cj = rv[j] / piv;
 #pragma nounroll
-                for (int k = 0; k < q; ++k) if (k != l) Ginv[(size_t)k * cap + j] -= rv[k] * cj;
+                for (int k = 0; k < q; ++k) if (k != l) Ginv[(size_t)k * ld + j] -= rv[k] * cj;
             }
             Z_MEMSYNC();
             if (l != last) {
-    #pragma nounroll
-            for (int j = lane; j < q; j += 64) {
+#pragma nounroll
+                for (int j = lane; j < q; j += 64) {
                     if (j == l) continue;
-                    const double vl_ = Ginv[(size_t)last * cap + j];
-                    Ginv[(size_t)l * cap + j] = vl_; Ginv[(size_t)j * cap + l] = vl_;
+                    const double vl_ = Ginv[(size_t)last * ld + j];
+                    Ginv[(size_t)l * ld + j] = vl_; Ginv[(size_t)j * ld + l] = vl_;
                 }
                 Z_MEMSYNC();
-                if (lane == 0) { Ginv[(size_t)l * cap + l] = Ginv[(size_t)last * cap + last]; arow[l] = arow[last]; asg[l] = asg[last]; amu[l] = amu[last]; }
+                if (lane == 0) { Ginv[(size_t)l * ld + l] = Ginv[(size_t)last * ld + last]; arow[l] = arow[last]; asg[l] = asg[last]; amu[l] = amu[last]; }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) if (n0 + r == drow) sact[r] = false;
@@ -771,7 +816,8 @@ __device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double
         }
         if (fail) { status |= ISMPC_ST_Z_FAILED; break; }
     }
-    z_slot_release(c, lane, slot);
+    if (slot >= 0) z_slot_release(c, lane, slot);
+    Z_MEMSYNC();                                             // the window is the caller's again
     return its;
 }
 
@@ -788,7 +834,7 @@ template <int R, bool FB>
 __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi, const int lane,
                                                  const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                                                  ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
-                                                 int rollout_frame, unsigned char* zmark, int launch_id, int* zlist = nullptr, int zbatch = 0)
+                                                 int rollout_frame, unsigned char* zmark, int launch_id, int* zlist = nullptr, int zbatch = 0, double* zlds = nullptr)
 {
     constexpr int NT = ismpc::Tables::NT;
     const int N = c.N;
@@ -853,7 +899,7 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
         const bool anyviol = __builtin_amdgcn_ballot_w64(viol) != 0;
         if (anyviol) {
             status |= ISMPC_ST_Z_INEQ_ACTIVE;
-            if constexpr (FB) zits = z_active_set<R>(c, lane, n0, pat, u, su, status, gi);
+            if constexpr (FB) zits = z_active_set<R>(c, lane, n0, pat, u, su, status, gi, zlds);
             else deferred = true;
         }
 #pragma unroll
@@ -1253,6 +1299,8 @@ struct QOut { double x, y, z, xd, yd, zd, uz0, ux0, uy0; int status, itx, ity; }
 // block starts at li * MIDM double2; MIDM is odd, which keeps the 16-byte reads of 16 lanes on 16 different bank quads.
 template <int R> constexpr int midm() { return R | 1; }
 template <int R, int LPI> constexpr int wave_lds_double2() { return (64 / LPI) * LPI * midm<R>(); }
+// ... and, in the kernels that run the inequality fallback themselves, at least the fallback's working window (z_active_set)
+template <int R, int LPI> constexpr int wave_lds_double2_fb() { return wave_lds_double2<R, LPI>() > (Z_LDS_DOUBLES + 1) / 2 ? wave_lds_double2<R, LPI>() : (Z_LDS_DOUBLES + 1) / 2; }
 
 // KF: how the knapsack Newton loop is scheduled, not what it computes (the iterates are bit-identical): 0 = count the saturated
 // samples first and form the two sums only for axes that still move (fewest instructions: batches that fill the chip are
@@ -1642,9 +1690,9 @@ void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, 
 // wavefront that does defer an instance pays for the call.
 template <int RW>
 __device__ __attribute__((noinline)) void fallback_call(const DevConst* cp, int gi, int lane, const ismpc_tick_in* in_ro, ismpc_tick_in* state_rw,
-                                                        ismpc_tick_out* out, double* u_traj, int rollout_frame, unsigned char* zmark, int launch_id)
+                                                        ismpc_tick_out* out, double* u_traj, int rollout_frame, unsigned char* zmark, int launch_id, double* zlds)
 {
-    tick_affine_body<RW, true>(*cp, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+    tick_affine_body<RW, true>(*cp, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, nullptr, 0, zlds);
 }
 
 // Latency variant for small batches (every wavefront resident at once): a wavefront that deferred one of its
@@ -1656,7 +1704,7 @@ void ismpc_tick_quad_inline(const DevConst c, const ismpc_tick_in* __restrict__ 
                             unsigned char* zmark, int launch_id, const DevConst* __restrict__ cdev)
 {
     constexpr int IPW = 64 / LPI;
-    __shared__ double2 lds_mid[ISMPC_QUAD_WAVES][wave_lds_double2<R, LPI>()];
+    __shared__ double2 lds_mid[ISMPC_QUAD_WAVES][wave_lds_double2_fb<R, LPI>()];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
@@ -1667,7 +1715,7 @@ void ismpc_tick_quad_inline(const DevConst c, const ismpc_tick_in* __restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     for (int q = 0; q < IPW; ++q)
         if ((m >> (LPI * q)) & 1ull)
-            fallback_call<RW>(cdev, wave * IPW + q, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);   // (the constants in memory:
+            fallback_call<RW>(cdev, wave * IPW + q, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, reinterpret_cast<double*>(lds_mid[wv]));   // (the constants in memory:
                                                                                      // taking the address of the by-value argument would move the hot path's copy to the stack)
 }
 
@@ -1686,7 +1734,7 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
                         int* __restrict__ stop_tick, int launch_id)
 {
     constexpr int IPW = 64 / LPI;
-    __shared__ double2 lds_mid[ISMPC_QUAD_WAVES][wave_lds_double2<R, LPI>()];
+    __shared__ double2 lds_mid[ISMPC_QUAD_WAVES][FB ? wave_lds_double2_fb<R, LPI>() : wave_lds_double2<R, LPI>()];
     const int lane = threadIdx.x & 63, li = lane & (LPI - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
@@ -1735,7 +1783,7 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     // (FB: one instance per wavefront, its set is wave-uniform and valid -- an invalid one never defers)
                     tick_affine_body<RW, true>(SW ? c.sets[__builtin_amdgcn_readfirstlane(max(s.ps, 0))] : c, gi, lane, nullptr, state,
-                                               traj ? traj + (size_t)t * batch : nullptr, nullptr, frame, nullptr, 0);
+                                               traj ? traj + (size_t)t * batch : nullptr, nullptr, frame, nullptr, 0, nullptr, 0, reinterpret_cast<double*>(lds_mid[wv]));
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     const volatile ismpc_tick_in* vr = rec;
                     s.x = vr->com_pos[0]; s.y = vr->com_pos[1]; s.z = vr->com_pos[2];
@@ -1768,8 +1816,11 @@ void ismpc_tick_affine_fallback(const DevConst c, const ismpc_tick_in* __restric
     int* zl = zlist_of(zmark, batch);
     if (blockIdx.x == 0 && threadIdx.x == 0) zl[batch + ((launch_id + 1) & 1)] = 0;       // the next launch's counter (its previous user, launch_id - 1, is done)
     if (*c.zflag != launch_id) return;
+    __shared__ double zlds[4][Z_LDS_DOUBLES];
     const int lane = threadIdx.x & 63;
-    const int wave0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave0 = blockIdx.x * 4 + wv;
+    double* const zwin = zlds[wv];
     const int ndef = min(zl[batch + (launch_id & 1)], batch);
     for (int k = wave0; k < ndef; k += gridDim.x * 4) {
         const int gi = __builtin_amdgcn_readfirstlane(zl[k]);
@@ -1777,8 +1828,8 @@ void ismpc_tick_affine_fallback(const DevConst c, const ismpc_tick_in* __restric
             if (SW) {
                 // one instance per wavefront: its parameter set is wave-uniform, the body runs on that set's own record
                 const int ps = __builtin_amdgcn_readfirstlane((((rollout_frame >= 0) ? state_rw : in_ro) + gi)->reserved);
-                tick_affine_body<R, true>(c.sets[ps], gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);    // (a deferred instance has a valid set)
-            } else tick_affine_body<R, true>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id);
+                tick_affine_body<R, true>(c.sets[ps], gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, nullptr, 0, zwin);    // (a deferred instance has a valid set)
+            } else tick_affine_body<R, true>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, nullptr, 0, zwin);
         }
     }
 }
