@@ -417,10 +417,18 @@ def one_launch(N, B, cus):
     path = os.environ.get("ISMPC_PATH")
     if path == "dense" or os.environ.get("ISMPC_Z_FALLBACK") == "0":
         return True
-    return (path != "wave" and N <= 128 and os.environ.get("ISMPC_ONE_LAUNCH") != "0" and (B * _lpi(B) + 63) // 64 <= 8 * cus)
+    mode = os.environ.get("ISMPC_ONE_LAUNCH", "2")                       # 2 (default): every batch size; 1: only batches resident at once; 0: never
+    if path == "wave" or N > 128 or mode == "0":
+        return False
+    return mode != "1" or _resident(B, cus)
 
 
-def kernel_name_b(N, B, cus):
+def _resident(B, cus):
+    """Every wavefront of the batch on the chip at once at two wavefronts per SIMD (the latency kernel ismpc_tick_quad_inline)."""
+    return (B * _lpi(B) + 63) // 64 <= 8 * cus
+
+
+def kernel_name_b(N, B, cus, sweep=False, deferring=False):
     path = os.environ.get("ISMPC_PATH")
     if path == "dense":
         return "ismpc_tick_dense<%d, 16>" % ((N + 63) // 64)
@@ -428,7 +436,16 @@ def kernel_name_b(N, B, cus):
         return "ismpc_tick_affine<%d>" % ((N + 63) // 64)
     lpi = _lpi(B)
     if one_launch(N, B, cus) and os.environ.get("ISMPC_Z_FALLBACK") != "0":
-        return "ismpc_tick_quad_inline<%d, %d, %d>" % (_quad_r(N, lpi), lpi, (N + 63) // 64)
+        # beyond the resident size the library goes back to two launches while instances are being deferred (launch() in csrc/ismpc_hip.hip)
+        big_one = not deferring or os.environ.get("ISMPC_ONE_LAUNCH") == "3"
+        if sweep and big_one:
+            return "ismpc_tick_quad_one<%d, 16, %d, true>" % (_quad_r(N, 16), (N + 63) // 64)
+        if not sweep and _resident(B, cus):
+            return "ismpc_tick_quad_inline<%d, %d, %d>" % (_quad_r(N, lpi), lpi, (N + 63) // 64)
+        if not sweep and big_one:
+            return "ismpc_tick_quad_one<%d, %d, %d, false>" % (_quad_r(N, lpi), lpi, (N + 63) // 64)
+    if sweep:
+        return "ismpc_tick_quad<%d, 16, true>" % _quad_r(N, 16)
     return "ismpc_tick_quad<%d, %d, false>" % (_quad_r(N, lpi), lpi)
 
 
@@ -478,9 +495,7 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
     # ---- dominant kernel alone (roofline): same inputs.  Two durations: a train of K back-to-back launches (per-launch
     # interval, event pair per region) and ONE launch between synchronisations (what rocprofv3 reports per dispatch)
     solo = solver
-    if sweep_sets > 0:
-        pass                                                             # (a sweep step is always two launches; the fallback is idle on this batch)
-    elif not one_launch(N, B, cus):
+    if not one_launch(N, B, cus) and sweep_sets == 0:
         os.environ["ISMPC_Z_FALLBACK"] = "0"                             # the normally idle second launch switched off
         try:
             solo = q.MPCSolver(q.reference_plan(params=p), params=p, device=R.local_rank)
@@ -511,7 +526,7 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
     if rank == 0:
         value = global_batch / (wall / K)
         flops = flops_b(N) * B
-        kname = kernel_name_b(N, B, cus) if sweep_sets == 0 else "ismpc_tick_quad<%d, 16, true>" % _quad_r(N, 16)
+        kname = kernel_name_b(N, B, cus, sweep=sweep_sets > 0, deferring=bool(((st & q.ST_Z_INEQ_ACTIVE) != 0).any()))
         res = {
             "value": value, "unit": "ticks/s (1 tick = one MPCSolver::solve = 3 QPs: vertical + x + y)",
             "ms_per_step": 1e3 * wall / K, "dtype": "f64", "qp_solves_per_s": 3.0 * value,
@@ -530,7 +545,9 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
                                  note="kernel_ms = ONE launch between synchronisations (HIP events; agrees with the rocprofv3 per-dispatch average under "
                                       "profiles/r03); kernel_ms_train = per-launch interval of back-to-back launches of the same kernel (consecutive "
                                       "launches overlap head to tail, so it is shorter and is what `value` is made of); step_interval_ms = the same for the "
-                                      "whole step (kernel + the normally idle fallback launch).  No MFMA on this path: bound = FP64 vector issue."),
+                                      "whole step (one launch while no instance has active vertical inequality rows; a batch beyond the resident size that "
+                                      "does defer instances takes two: the tick kernel, then one wavefront per deferred instance).  No MFMA on this "
+                                      "path: bound = FP64 vector issue."),
         }
         if pipe is not None:
             res["multi_gpu"] = {"kernel_ms": kernel_ms_train, "collective_ms": collective_ms, "overlapped_step_ms": 1e3 * wall / K}

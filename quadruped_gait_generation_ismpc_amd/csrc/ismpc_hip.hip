@@ -59,8 +59,9 @@ struct DevConst {
     const DevConst* sets; int nsets;  // parameter sweeps (ismpc_create_sweep): one record per parameter set, its own tables and scalars; the
                                       // instance's record names its set (ismpc_tick_in.reserved).  NULL / 0 for a plain handle
     int* zflag;                       // id of the last launch that deferred an instance to the fallback kernel
+    int* zseen;                       // the same id in a word of host memory (written, never read, by the device): how the host picks the launch form
     double* zpool; int* zbusy;        // active-set fallback: slots of zstride doubles (G^-1 cap x cap + per-entry vectors), one lock word per slot
-    int zslots, zcap; size_t zstride;
+    int zslots, zcap, zldsq; size_t zstride;   // zldsq: entries the fallback keeps in its LDS window before it moves to a slot (Z_LDS_Q; ISMPC_Z_LDS_Q lowers it: tests)
     // sample-major copies for ismpc_tick_quad: a lane's R samples are one contiguous run (16-byte loads, one base address)
     const double *vq;                 // (npat+1) x NT x 6 : U0,Ua,Ub,SU0,SUa,SUb per sample
     const double *tzg;                // NT x 2 : tz, tg per sample
@@ -664,7 +665,7 @@ __device__ int z_active_set(const DevConst& c, int lane, int n0, int pat, double
     int elo = 0, ne = 0;
     if (pat < c.npat) { elo = c.e_lo[pat]; ne = c.ne[pat]; }
     const double tol_lo = 1e-11 * fmax(1.0, fabs(c.z_lo)), tol_hi = 1e-11 * fmax(1.0, fabs(c.z_hi));
-    ZStore z; z.bind(lds, Z_LDS_Q);
+    ZStore z; z.bind(lds, c.zldsq);
     int slot = -1;
     bool sact[R];
 #pragma unroll
@@ -1659,7 +1660,7 @@ __device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_
     if ((lane & (LPI - 1)) == 0 && valid) {
         if (out) store_record(out + gi, o);
         if (zmark) zmark[gi] = deferred ? 1 : 0;
-        if (deferred) { atomicMax(c.zflag, launch_id); if (zlist) zlist[atomicAdd(zlist + batch + (launch_id & 1), 1)] = gi; }
+        if (deferred) { atomicMax(c.zflag, launch_id); if (c.zseen) *c.zseen = launch_id; if (zlist) zlist[atomicAdd(zlist + batch + (launch_id & 1), 1)] = gi; }
         if (rollout_frame >= 0 && !deferred) store_feedback(c, state_rw + gi, o, s.w);
     }
     STAMP(5);                                         // stores issued
@@ -1717,6 +1718,45 @@ void ismpc_tick_quad_inline(const DevConst c, const ismpc_tick_in* __restrict__ 
         if ((m >> (LPI * q)) & 1ull)
             fallback_call<RW>(cdev, wave * IPW + q, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, reinterpret_cast<double*>(lds_mid[wv]));   // (the constants in memory:
                                                                                      // taking the address of the by-value argument would move the hot path's copy to the stack)
+}
+
+// The one-launch form for batches that do NOT fit the chip at once: the tick keeps the three wavefronts per SIMD of ismpc_tick_quad
+// (the kernel asks for them, and the compiler hands that register budget down to the fallback it calls: the fallback spills to
+// scratch instead, and only a wavefront that defers an instance runs it).  No second, normally idle, launch per step: +1-2 % at
+// 65 536 instances, +4 % at 32 768, +8 % at 16 384 (same box, scripts/ab_env.sh ISMPC_ONE_LAUNCH=0).  SW: parameter sweeps, the
+// fallback runs on the deferred instance's own set.
+// wavefronts per SIMD of ismpc_tick_quad<R, LPI, SW> (profiles/r03/kernel_resources.md): what the one-launch form asks for
+template <int R, bool SW> constexpr int one_occ() { return R <= 4 ? (SW ? 3 : 4) : R <= 7 ? 3 : R == 8 ? (SW ? 2 : 3) : R <= 13 ? 2 : 1; }
+template <int RW, int OCC>        // OCC: one copy per residency target (the register budget comes down from the calling kernels)
+__device__ __attribute__((noinline))
+void fallback_call_one(const DevConst* cp, int gi, int lane, const ismpc_tick_in* in_ro, ismpc_tick_in* state_rw,
+                       ismpc_tick_out* out, double* u_traj, int rollout_frame, unsigned char* zmark, int launch_id, double* zlds)
+{
+    tick_affine_body<RW, true>(*cp, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, nullptr, 0, zlds);
+}
+template <int R, int LPI, int RW, bool SW>
+__global__ __launch_bounds__(64 * ISMPC_QUAD_WAVES, (one_occ<R, SW>()))
+void ismpc_tick_quad_one(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
+                         ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
+                         unsigned char* zmark, int launch_id, const DevConst* __restrict__ cdev)
+{
+    constexpr int IPW = 64 / LPI;
+    __shared__ double2 lds_mid[ISMPC_QUAD_WAVES][wave_lds_double2_fb<R, LPI>()];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
+    if (wave * IPW >= batch) return;
+    const bool def = tick_group_body<R, LPI, ISMPC_KF_MAIN, SW>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
+    unsigned long long m = __builtin_amdgcn_ballot_w64(def);
+    if (m == 0ull) return;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int q = 0; q < IPW; ++q)
+        if ((m >> (LPI * q)) & 1ull) {
+            const int gi = wave * IPW + q;
+            const DevConst* cp = cdev;
+            if (SW) cp = c.sets + __builtin_amdgcn_readfirstlane((((rollout_frame >= 0) ? state_rw : in_ro) + gi)->reserved);   // (a deferred instance has a valid set)
+            fallback_call_one<RW, one_occ<R, SW>()>(cp, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, reinterpret_cast<double*>(lds_mid[wv]));
+        }
 }
 
 // Closed loop inside ONE launch (Controller.cpp:297-310 bookkeeping, :346-348 feedback, :503-504 counters): instances are
@@ -1866,6 +1906,8 @@ struct ismpc_handle {
     int host_mode = 3;                                          // ISMPC_HOST_MODE: bit 0 = kernel reads page-locked caller records in place, bit 1 = writes them in place
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false; bool timed_pending = false; double last_ms = 0.0;
+    int* zseen_host = nullptr; // DevConst::zseen as the host sees it
+    int one_launch = 2;       // 2: one launch per step (ismpc_tick_quad_inline up to the resident size; beyond it ismpc_tick_quad_one unless recent launches deferred instances); 1: only the former; 0: never; 3: always
     int force_waves = 0;      // dense path: 4, 8 or 16 wavefronts per workgroup (0 = 16)
     unsigned char* zmark = nullptr; int zmark_cap = 0; int launch_id = 0; bool z_fallback = true;
     int zlist_batch = -1;        // batch whose deferred-list counters (inside the zmark allocation, at batch-dependent offsets) are initialised
@@ -1954,6 +1996,15 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
         unsigned char* zm = h->z_fallback ? h->zmark : nullptr;
         const int lid = ++h->launch_id;
         const dim3 fgrid(std::min((batch + 3) / 4, 256));      // the fallback walks the list of deferred instances: one wavefront each
+        // Batches beyond the resident size: ONE launch (ismpc_tick_quad_one: a wavefront that defers an instance runs the fallback for it
+        // itself) while nothing is being deferred -- the usual case, and the second launch would be idle; TWO launches (the deferred
+        // list, one wavefront per deferred instance at the fallback's own register budget) when one of the last few launches did defer:
+        // measured on the sweep batch (0.4 % deferred) 70.5 against 75.8 us per step.  The kernels leave the id of a deferring launch in
+        // a word of host memory; reading it here costs nothing.  The host enqueues far ahead of the device (a closed loop of per-tick
+        // launches is hundreds of launches deep), so the word is stale by that much: `recent` is the last 4 096 launches.  Both forms
+        // give the same bytes, so a late switch costs microseconds, never correctness.
+        const bool recent_deferrals = h->zseen_host && *(volatile int*)h->zseen_host != 0 && lid - *(volatile int*)h->zseen_host <= 4096;
+        const bool one_big = zm && (h->one_launch == 3 || (h->one_launch == 2 && !recent_deferrals));
         // default for N <= 128: several instances per wavefront (ismpc_tick_quad); ISMPC_PATH=wave keeps one per wavefront
         if (h->quad_path && h->c.N <= 128) {
             const bool small = h->lpi_auto && h->vqT32 && batch <= LPI32_BATCH;
@@ -1963,7 +2014,14 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
             const int waves = (batch * lpi + 63) / 64;
             const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
             if (h->sweep) {
-                // parameter sweep: the per-tick kernel reads each instance's set through c.sets (16 lanes per instance), two-launch form
+                // parameter sweep: the per-tick kernel reads each instance's set through c.sets (16 lanes per instance)
+                if (one_big) {
+#define ISMPC_QUADS1(RR, RW_) hipLaunchKernelGGL((ismpc_tick_quad_one<RR, 16, RW_, true>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid, (const DevConst*)h->c_dev)
+                    if (RQ == 4) ISMPC_QUADS1(4, 1); else if (RQ == 7) ISMPC_QUADS1(7, 2); else ISMPC_QUADS1(8, 2);
+#undef ISMPC_QUADS1
+                    HIP_TRY(hipGetLastError());
+                    return ISMPC_OK;
+                }
 #define ISMPC_QUADS(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad<RR, 16, true>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid)
                 if (RQ == 4) ISMPC_QUADS(4, 16, 1); else if (RQ == 7) ISMPC_QUADS(7, 16, 2); else ISMPC_QUADS(8, 16, 2);
 #undef ISMPC_QUADS
@@ -1975,10 +2033,17 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
                 return ISMPC_OK;
             }
             // every wavefront resident at once (<= 2 per SIMD) and a fallback to run: one launch that handles deferred instances itself
-            if (zm && h->cus > 0 && waves <= 8 * h->cus) {
+            if (zm && h->one_launch >= 1 && h->cus > 0 && waves <= 8 * h->cus) {
 #define ISMPC_QUADI(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad_inline<RR, LL, RW_>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid, (const DevConst*)h->c_dev)
                 ISMPC_SHAPES(ISMPC_QUADI)
 #undef ISMPC_QUADI
+                HIP_TRY(hipGetLastError());
+                return ISMPC_OK;
+            }
+            if (one_big) {                  // any other batch size: one launch too, at the tick's own three wavefronts per SIMD
+#define ISMPC_QUADB(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad_one<RR, LL, RW_, false>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid, (const DevConst*)h->c_dev)
+                ISMPC_SHAPES(ISMPC_QUADB)
+#undef ISMPC_QUADB
                 HIP_TRY(hipGetLastError());
                 return ISMPC_OK;
             }
@@ -2089,7 +2154,7 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
     DeviceGuard guard_(device);
     if (guard_.err != hipSuccess) { delete h; return fail(ISMPC_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard_.err)); }
     { hipDeviceProp_t prop; h->cus = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0; }
-    if (const char* fu = std::getenv("ISMPC_ONE_LAUNCH")) { if (std::atoi(fu) == 0) h->cus = 0; }    // 0: always two launches (A/B)
+    if (const char* fu = std::getenv("ISMPC_ONE_LAUNCH")) h->one_launch = std::max(0, std::min(3, std::atoi(fu)));    // A/B: 0 = always two launches, 1 = one launch only for batches resident at once, 3 = always one    // 0: always two launches (A/B)
     const ismpc::Tables& t = h->t;
     DevConst& c = h->c;
     c.N = t.p.N; c.NP = t.NP; c.NPs = t.NP + 2; c.S = t.p.S; c.F = t.p.F; c.nmid = t.nmid; c.npat = t.npat;
@@ -2121,8 +2186,16 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
     if (rc == ISMPC_OK) rc = upload(h, t.SHSt, &c.SHSt);
     if (rc == ISMPC_OK) { std::vector<int> zf(1, 0); const int* zp = nullptr; rc = upload(h, zf, &zp); c.zflag = const_cast<int*>(zp); }
     if (rc == ISMPC_OK) {
+        // one word of page-locked host memory the kernels write the launch id to when they defer an instance (see launch())
+        void* hp = nullptr; void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            h->zseen_host = static_cast<int*>(hp); *h->zseen_host = 0; c.zseen = static_cast<int*>(dp);
+        } else { if (hp) (void)hipHostFree(hp); (void)hipGetLastError(); c.zseen = nullptr; }
+    }
+    if (rc == ISMPC_OK) {
         // active-set fallback pool: 256 slots of (cap x cap + 4 cap + NT) doubles + cap ints, cap = N rows (every row may be active)
-        c.zslots = 256; c.zcap = t.p.N;
+        c.zslots = 256; c.zcap = t.p.N; c.zldsq = Z_LDS_Q;
+        if (const char* e = std::getenv("ISMPC_Z_LDS_Q")) c.zldsq = std::min(Z_LDS_Q, std::max(1, std::atoi(e)));
         c.zstride = (size_t)c.zcap * c.zcap + 4 * (size_t)c.zcap + ismpc::Tables::NT + ((size_t)c.zcap + 1) / 2 + 8;
         std::vector<int> busy(c.zslots, 0); const int* bp = nullptr;
         rc = upload(h, busy, &bp); c.zbusy = const_cast<int*>(bp);
@@ -2275,6 +2348,7 @@ void ismpc_destroy(ismpc_handle* h)
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->st_in) (void)hipFree(h->st_in);
     if (h->st_out) (void)hipFree(h->st_out);
+    if (h->zseen_host) (void)hipHostFree(h->zseen_host);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->zmark) (void)hipFree(h->zmark);

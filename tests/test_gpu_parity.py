@@ -179,6 +179,26 @@ def test_vertical_inequality_rows_active(q, O, N, over, dz, lay):
     assert ((out["iters"][act & ok] >> 16) & 255).min() >= 1   # fallback iterations are reported
 
 
+@pytest.mark.parametrize("N,over,dz", [(100, dict(z_ineq_hi=3.2), 0.0), (50, dict(), 0.12), (100, dict(), 0.25)])
+def test_fallback_working_set_moves_to_the_pool(q, N, over, dz, monkeypatch):
+    """The fallback keeps its working set (G^-1, multipliers) in the wavefront's LDS window and moves it to a pool slot in HBM when it
+    outgrows the window (16 entries).  With the window cut to 2 entries (ISMPC_Z_LDS_Q) every solve with three active rows goes
+    through the move: where the working set lives does not change one bit of the result."""
+    from quadruped_gait_generation_ismpc_amd import workload
+    tin = workload.make_batch(150 if N == 150 else (100 if N >= 100 else 50), 96, seed=77 + N)
+    tin["com_pos"][:, 2] += dz
+    tin["com_vel"][:, 2] += 0.2 * np.sign(dz)
+    p = q.default_params(N=N, **over)
+    ftsp = q.reference_plan(params=p)
+    ref = q.MPCSolver(ftsp, params=p).solve_batch(tin)
+    monkeypatch.setenv("ISMPC_Z_LDS_Q", "2")
+    out = q.MPCSolver(ftsp, params=p).solve_batch(tin)
+    zits = (ref["iters"] >> 16) & 255
+    assert (zits >= 3).sum() >= 8, zits.max()                   # working sets beyond two entries exist in this batch
+    assert ((out["status"] & q.ST_Z_FAILED) == 0).all()
+    assert out.tobytes() == ref.tobytes()
+
+
 @pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("N", [50, 100, 150])
 def test_non_flat_plan(q, O, N, path):
@@ -400,6 +420,42 @@ def test_bitwise_reproducible_across_launch_variants_of_one_path(q, batch):
     o1 = s.solve_batch_torch(d_in).clone(); o2 = s.solve_batch_torch(d_in).clone()
     torch.cuda.synchronize()
     assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("sweep", [False, True])
+def test_one_launch_and_two_launch_forms_agree_bitwise(q, sweep, monkeypatch):
+    """A batch beyond the resident size takes ismpc_tick_quad_one: a wavefront that defers an instance (active vertical inequality rows)
+    runs the fallback for it itself, on the instance's own parameter set in a sweep.  ISMPC_ONE_LAUNCH=0 is the two-launch form
+    (ismpc_tick_quad + the deferred list + ismpc_tick_affine_fallback).  Same arithmetic: byte-identical records, also through ten
+    ticks of the host-driven closed loop (state fed back in place, Controller.cpp:346-348)."""
+    import torch
+    from quadruped_gait_generation_ismpc_amd import workload
+    B = 40000
+    tin = workload.make_batch(100, B, seed=55)
+    monkeypatch.setenv("ISMPC_ROLLOUT", "host")
+    if sweep:
+        sets = workload.make_sweep_params(8, N=100)
+        for p in sets:
+            p.z_ineq_hi = 4.6
+        plan = q.reference_plan(params=sets[0])
+        tin["reserved"] = np.arange(B) % 8
+        make = lambda: q.MPCSolver.sweep(plan, sets)
+    else:
+        p = q.default_params(N=100, z_ineq_hi=4.6)
+        plan = q.reference_plan(params=p)
+        make = lambda: q.MPCSolver(plan, params=p)
+    monkeypatch.setenv("ISMPC_ONE_LAUNCH", "3")           # (the default switches to two launches while instances are being deferred)
+    one = make()
+    monkeypatch.setenv("ISMPC_ONE_LAUNCH", "0")
+    two = make()
+    a, b = one.solve_batch(tin), two.solve_batch(tin)
+    act = (a["status"] & q.ST_Z_INEQ_ACTIVE) != 0
+    assert act.sum() > 100 and ((a["status"] & q.ST_Z_FAILED) == 0).all()
+    assert a.tobytes() == b.tobytes()
+    sa, sb = q.to_device(tin), q.to_device(tin)
+    ta = one.rollout_torch(sa, int(tin["simulation_time"].max()) + 1, 10); tb = two.rollout_torch(sb, int(tin["simulation_time"].max()) + 1, 10)
+    torch.cuda.synchronize()
+    assert torch.equal(ta, tb) and torch.equal(sa, sb)
 
 
 @pytest.mark.parametrize("lay,host", [("affine", "hostloop"), ("lpi8", "hostloop8"), ("lpi32", "hostloop32")])
