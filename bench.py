@@ -495,10 +495,13 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
     # ---- dominant kernel alone (roofline): same inputs.  Two durations: a train of K back-to-back launches (per-launch
     # interval, event pair per region) and ONE launch between synchronisations (what rocprofv3 reports per dispatch)
     solo = solver
-    if not one_launch(N, B, cus) and sweep_sets == 0:
-        os.environ["ISMPC_Z_FALLBACK"] = "0"                             # the normally idle second launch switched off
+    deferring = bool(((q.from_device(d_out[0], q.TICK_OUT)["status"] & q.ST_Z_INEQ_ACTIVE) != 0).any())
+    two_launches = not one_launch(N, B, cus) or (deferring and not _resident(B, cus) and os.environ.get("ISMPC_ONE_LAUNCH") != "3")
+    if two_launches:
+        os.environ["ISMPC_Z_FALLBACK"] = "0"                             # the tick kernel alone: the second launch (fallback) switched off
         try:
-            solo = q.MPCSolver(q.reference_plan(params=p), params=p, device=R.local_rank)
+            solo = (q.MPCSolver.sweep(q.reference_plan(params=p), workload.make_sweep_params(sweep_sets, N=N), device=R.local_rank) if sweep_sets > 0
+                    else q.MPCSolver(q.reference_plan(params=p), params=p, device=R.local_rank))
         finally:
             del os.environ["ISMPC_Z_FALLBACK"]
     d_tmp = torch.empty_like(d_out[0])
@@ -526,7 +529,7 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
     if rank == 0:
         value = global_batch / (wall / K)
         flops = flops_b(N) * B
-        kname = kernel_name_b(N, B, cus, sweep=sweep_sets > 0, deferring=bool(((st & q.ST_Z_INEQ_ACTIVE) != 0).any()))
+        kname = kernel_name_b(N, B, cus, sweep=sweep_sets > 0, deferring=deferring)
         res = {
             "value": value, "unit": "ticks/s (1 tick = one MPCSolver::solve = 3 QPs: vertical + x + y)",
             "ms_per_step": 1e3 * wall / K, "dtype": "f64", "qp_solves_per_s": 3.0 * value,

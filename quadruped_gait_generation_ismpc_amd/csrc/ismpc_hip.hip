@@ -2147,8 +2147,8 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
     if (const char* zf = std::getenv("ISMPC_Z_FALLBACK")) h->z_fallback = std::atoi(zf) != 0;   // 0: flag only, no second launch
     if (const char* lp = std::getenv("ISMPC_LPI")) { const int v = std::atoi(lp); if (v == 8 || v == 16 || v == 32) { h->lpi = v; h->lpi_auto = false; } }
     if (const char* ro = std::getenv("ISMPC_ROLLOUT")) h->kernel_rollout = std::strcmp(ro, "host") != 0;
-    if (sweep) {      // one kernel shape: 16 lanes per instance, two-launch form
-        h->sweep = true; h->lpi = 16; h->lpi_auto = false; h->quad_path = true; h->dense_path = false; h->z_fallback = true;
+    if (sweep) {      // one kernel shape: 16 lanes per instance (ISMPC_Z_FALLBACK=0 still means flag-only: bench.py times the tick kernel alone with it)
+        h->sweep = true; h->lpi = 16; h->lpi_auto = false; h->quad_path = true; h->dense_path = false;
         h->sets.assign(params, params + K); h->ftsp.assign(ftsp, ftsp + (size_t)rows * 4);
     }
     DeviceGuard guard_(device);
