@@ -58,6 +58,11 @@ for key, name, kern in LEGS:
                f"{fmt(traffic / 1e6 if traffic else None, 1)} MB / {alg / 1e6:.1f} MB | {r['algorithmic_credit']['tflops']:.1f} |")
 h = line(os.path.join(P, "bench_full_line.json")) or line(os.path.join(P, "headline_b65536_bench_line_unprofiled.json"))
 extra = []
+if h and "steps" in h and h.get("regions"):
+    r = h["roofline"]
+    extra.append(f"The default `python bench.py` of the same session ({h['steps']} steps per region, {h['regions']} regions: the table's legs are the short profiled runs, "
+                 f"40 steps, 5 ms regions, and the chip clocks higher in the long one): **{h['value']:.3g} ticks/s**, {h['ms_per_step'] * 1e3:.1f} µs per step, "
+                 f"`{r['kernel']}` {r['kernel_ms'] * 1e3:.1f} µs isolated / {r['kernel_ms_train'] * 1e3:.1f} µs in a train, `frac` {r.get('frac') or 0:.3f}.")
 if h:
     extra.append(f"Host entry point `ismpc_solve_batch`, 65 536 records in and out: page-locked caller buffers (zero copy) **{h.get('value_incl_pcie', 0):.3g} ticks/s** "
                  f"({h.get('ms_per_step_incl_pcie', 0):.3f} ms), pageable buffers (staged) {h.get('value_incl_pcie_pageable', 0):.3g} ticks/s ({h.get('ms_per_step_incl_pcie_pageable', 0):.3f} ms); "
