@@ -397,9 +397,10 @@ def flops_a(C, F, w):
 
 
 def _lpi(B):
-    """csrc/ismpc_hip.hip launch(): lanes per instance of the lane-group kernels (ISMPC_LPI, else 32 for batches <= 2 048, 16 above)."""
+    """csrc/ismpc_hip.hip pick_layout(): lanes per instance of the lane-group kernels (ISMPC_LPI, else 32 for batches <= 2 048, 16 up to
+    8 192, 8 above)."""
     forced = {"8": 8, "16": 16, "32": 32}.get(os.environ.get("ISMPC_LPI"))
-    return forced if forced else (32 if B <= 2048 else 16)
+    return forced if forced else (32 if B <= 2048 else (16 if B <= 8192 else 8))
 
 
 def _quad_r(N, lpi):
@@ -435,17 +436,18 @@ def kernel_name_b(N, B, cus, sweep=False, deferring=False):
     if path == "wave" or N > 128:
         return "ismpc_tick_affine<%d>" % ((N + 63) // 64)
     lpi = _lpi(B)
+    slpi = 8 if (B > 8192 and os.environ.get("ISMPC_LPI") == "8") else 16   # sweep handles: 16 lanes per instance (ISMPC_LPI=8: 8 beyond 8 192, measured no faster)
     if one_launch(N, B, cus) and os.environ.get("ISMPC_Z_FALLBACK") != "0":
         # beyond the resident size the library goes back to two launches while instances are being deferred (launch() in csrc/ismpc_hip.hip)
         big_one = not deferring or os.environ.get("ISMPC_ONE_LAUNCH") == "3"
         if sweep and big_one:
-            return "ismpc_tick_quad_one<%d, 16, %d, true>" % (_quad_r(N, 16), (N + 63) // 64)
+            return "ismpc_tick_quad_one<%d, %d, %d, true>" % (_quad_r(N, slpi), slpi, (N + 63) // 64)
         if not sweep and _resident(B, cus):
             return "ismpc_tick_quad_inline<%d, %d, %d>" % (_quad_r(N, lpi), lpi, (N + 63) // 64)
         if not sweep and big_one:
             return "ismpc_tick_quad_one<%d, %d, %d, false>" % (_quad_r(N, lpi), lpi, (N + 63) // 64)
     if sweep:
-        return "ismpc_tick_quad<%d, 16, true>" % _quad_r(N, 16)
+        return "ismpc_tick_quad<%d, %d, true>" % (_quad_r(N, slpi), slpi)
     return "ismpc_tick_quad<%d, %d, false>" % (_quad_r(N, lpi), lpi)
 
 

@@ -178,7 +178,11 @@ int ismpc_solve_batch_device(ismpc_handle* h, int batch,
  * output back as the next input (Controller.cpp:346-348), then
  * ++controlIter, mpcIter = floor(controlIter*cdt/dt) (Controller.cpp:503-504).
  * `state` (device, batch records) is updated in place; `traj` is NULL or a
- * device buffer of ticks x batch ismpc_tick_out records.                    */
+ * device buffer of ticks x batch ismpc_tick_out records.
+ * The kernels pick the number of lanes per instance by batch size, and the
+ * closed loop and the single tick pick differently beyond 8 192 instances per
+ * call: a rollout tick and an ismpc_solve_batch* tick of the same state then
+ * agree to rounding (sums taken in another order), not to the byte.          */
 int ismpc_rollout_device(ismpc_handle* h, int batch, ismpc_tick_in* state_dev,
                          int first_frame, int ticks, ismpc_tick_out* traj_dev,
                          void* stream);

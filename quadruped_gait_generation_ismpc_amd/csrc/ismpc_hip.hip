@@ -1919,6 +1919,8 @@ struct ismpc_handle {
     bool lpi_auto = true;     // no ISMPC_LPI: 32 lanes per instance for batches of <= LPI32_BATCH instances (scripts/lpi_batch.py: 1 us of 9-10
                               // there, slower from 3 072 on), 16 otherwise; the tables exist in both layouts
     const double* vqT32 = nullptr; const double* tzgT32 = nullptr;
+    const double* vqT8 = nullptr; const double* tzgT8 = nullptr;     // ... and 8 lanes per instance beyond LPI16_BATCH instances per launch
+    const DevConst* sets8 = nullptr;                                  // sweep handles: the set records with the 8-lane tables (null: 16 lanes at every batch size)
     bool kernel_rollout = true;   // closed loops run inside one launch (ismpc_rollout_quad); ISMPC_ROLLOUT=host: one launch per tick
     DevConst* c_dev = nullptr;    // the constants in device memory (the one-launch kernel's fallback call reads them there)
     bool sweep = false;           // ismpc_create_sweep: K parameter sets, tables built on the device (csrc/ismpc_sweep.hip)
@@ -1944,6 +1946,13 @@ int upload(ismpc_handle* h, const std::vector<T>& v, const T** dst)
 // Shape of the lane-group kernels for horizon N: samples per lane R (the smallest instantiated value that covers N) for
 // LPI = 16 / 8 lanes per instance; RW = samples per lane of the one-instance-per-wavefront fallback body.
 constexpr int LPI32_BATCH = 2048;
+// ... 8 lanes per instance (eight instances per wavefront, 13 samples per lane at N = 100, two wavefronts per SIMD) beyond this many:
+// a launch that does not fit the chip at once is bound by the instructions it issues, and a group reduction or scan step serves twice
+// the instances (round 3, one box: 65 536 instances 1.30-1.35 -> 1.41-1.44e9 ticks/s, 32 768 1.18 -> 1.24e9, 16 384 0.94 -> 1.03e9;
+// 8 192 level, 1 024 slower)
+constexpr int LPI16_BATCH = 8192;
+struct LaneLayout { int lpi; const double* vqT; const double* tzgT; };
+LaneLayout pick_layout(const ismpc_handle* h, int batch, bool per_tick);
 int quad_R(int N, int lpi)
 {
     const int need = (N + lpi - 1) / lpi;
@@ -1958,6 +1967,17 @@ int quad_R(int N, int lpi)
 
 // Scratch that outlives the call that allocated it (zmark, zstop) is used by later calls on whatever stream those pass: before
 // it is re-allocated on stream `s`, the previous launch's stream -- if it is another one -- is drained.
+// Lanes per instance of a launch of `batch` instances (the handle's own layout unless it chooses per launch: no ISMPC_LPI, no sweep).
+// per_tick = false: the closed loop (ismpc_rollout_device, in the kernel or one launch per tick) keeps the 16-lane shape beyond LPI32_BATCH --
+// with the state in registers across ticks it is the faster one there too (65 536 instances: 1.72 against 1.61e9 ticks/s).  Layouts differ in
+// summation order, i.e. in the last bits: a tick of ismpc_solve_batch* and a tick of a rollout agree to rounding, not to the byte, beyond
+// LPI16_BATCH instances per launch.
+LaneLayout pick_layout(const ismpc_handle* h, int batch, bool per_tick)
+{
+    if (h->lpi_auto && h->vqT32 && batch <= LPI32_BATCH) return {32, h->vqT32, h->tzgT32};
+    if ((h->lpi_auto || (h->sweep && h->sets8)) && h->vqT8 && per_tick && batch > LPI16_BATCH) return {8, h->vqT8, h->tzgT8};
+    return {h->lpi, h->c.vqT, h->c.tzgT};
+}
 hipError_t grow_sync(ismpc_handle* h, hipStream_t s)
 {
     if (h->used && h->last_stream != s) return hipStreamSynchronize(h->last_stream);
@@ -2007,24 +2027,29 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
         const bool one_big = zm && (h->one_launch == 3 || (h->one_launch == 2 && !recent_deferrals));
         // default for N <= 128: several instances per wavefront (ismpc_tick_quad); ISMPC_PATH=wave keeps one per wavefront
         if (h->quad_path && h->c.N <= 128) {
-            const bool small = h->lpi_auto && h->vqT32 && batch <= LPI32_BATCH;
-            const int lpi = small ? 32 : h->lpi, RQ = quad_R(h->c.N, lpi);
+            const LaneLayout lay = pick_layout(h, batch, rollout_frame < 0);      // (a closed loop driven from the host keeps the in-kernel loop's layout: same bytes)
+            const int lpi = lay.lpi, RQ = quad_R(h->c.N, lpi);
             DevConst cq = h->c;
-            if (small) { cq.vqT = h->vqT32; cq.tzgT = h->tzgT32; }
+            cq.vqT = lay.vqT; cq.tzgT = lay.tzgT;
             const int waves = (batch * lpi + 63) / 64;
             const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
             if (h->sweep) {
-                // parameter sweep: the per-tick kernel reads each instance's set through c.sets (16 lanes per instance)
+                // parameter sweep: the per-tick kernel reads each instance's set through c.sets (16 lanes per instance, 8 beyond LPI16_BATCH)
+                if (lpi == 8) cq.sets = h->sets8;
+#define ISMPC_SWEEP_SHAPES(X) \
+    if (lpi == 16) { if (RQ == 4) X(4, 16, 1); else if (RQ == 7) X(7, 16, 2); else X(8, 16, 2); } \
+    else           { if (RQ == 8) X(8, 8, 1);   else if (RQ == 13) X(13, 8, 2); else X(16, 8, 2); }
                 if (one_big) {
-#define ISMPC_QUADS1(RR, RW_) hipLaunchKernelGGL((ismpc_tick_quad_one<RR, 16, RW_, true>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid, (const DevConst*)h->c_dev)
-                    if (RQ == 4) ISMPC_QUADS1(4, 1); else if (RQ == 7) ISMPC_QUADS1(7, 2); else ISMPC_QUADS1(8, 2);
+#define ISMPC_QUADS1(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad_one<RR, LL, RW_, true>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid, (const DevConst*)h->c_dev)
+                    ISMPC_SWEEP_SHAPES(ISMPC_QUADS1)
 #undef ISMPC_QUADS1
                     HIP_TRY(hipGetLastError());
                     return ISMPC_OK;
                 }
-#define ISMPC_QUADS(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad<RR, 16, true>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid)
-                if (RQ == 4) ISMPC_QUADS(4, 16, 1); else if (RQ == 7) ISMPC_QUADS(7, 16, 2); else ISMPC_QUADS(8, 16, 2);
+#define ISMPC_QUADS(RR, LL, RW_) hipLaunchKernelGGL((ismpc_tick_quad<RR, LL, true>), qgrid, qblock, 0, s, cq, in, state, out, u_traj, batch, rollout_frame, zm, lid)
+                ISMPC_SWEEP_SHAPES(ISMPC_QUADS)
 #undef ISMPC_QUADS
+#undef ISMPC_SWEEP_SHAPES
                 if (zm) {
                     if (R == 1) hipLaunchKernelGGL((ismpc_tick_affine_fallback<1, true>), fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid);
                     else        hipLaunchKernelGGL((ismpc_tick_affine_fallback<2, true>), fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid);
@@ -2219,9 +2244,9 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
         if (rc == ISMPC_OK) rc = upload(h, mxy, &c.midxy);
         if (rc == ISMPC_OK && t.p.N <= 128) {
             // lane-contiguous copies for the lane-group kernels' shapes (sample li*R + r of pattern p): the handle's layout and,
-            // when the layout is chosen per launch, the 32-lane one beside it
-            for (int pass = 0; pass < (h->lpi_auto ? 2 : 1) && rc == ISMPC_OK; ++pass) {
-                const int lpi = pass == 0 ? h->lpi : 32, R = quad_R(t.p.N, lpi);
+            // when the layout is chosen per launch, the 32-lane and the 8-lane one beside it
+            for (int pass = 0; pass < ((h->lpi_auto || sweep) ? 3 : 1) && rc == ISMPC_OK; ++pass) {
+                const int lpi = pass == 0 ? h->lpi : (pass == 1 ? 32 : 8), R = quad_R(t.p.N, lpi);
                 std::vector<double> vqT(npp * (size_t)R * 3 * lpi * 2), tzgT((size_t)R * lpi * 2);
                 for (size_t pp = 0; pp < npp; ++pp)
                     for (int r = 0; r < R; ++r)
@@ -2233,8 +2258,8 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
                             }
                 for (int r = 0; r < R; ++r)
                     for (int li = 0; li < lpi; ++li) { const int n = li * R + r; tzgT[((size_t)r * lpi + li) * 2] = t.tz[n]; tzgT[((size_t)r * lpi + li) * 2 + 1] = t.tg[n]; }
-                rc = upload(h, vqT, pass == 0 ? &c.vqT : &h->vqT32);
-                if (rc == ISMPC_OK) rc = upload(h, tzgT, pass == 0 ? &c.tzgT : &h->tzgT32);
+                rc = upload(h, vqT, pass == 0 ? &c.vqT : (pass == 1 ? &h->vqT32 : &h->vqT8));
+                if (rc == ISMPC_OK) rc = upload(h, tzgT, pass == 0 ? &c.tzgT : (pass == 1 ? &h->tzgT32 : &h->tzgT8));
             }
         }
     }
@@ -2247,7 +2272,11 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
         // every set's tables, built on the device (MFMA Newton-Schulz inverse of the K vertical Hessians, csrc/ismpc_sweep.hip), and one
         // DevConst record per set: the handle's, with the set's scalars and table pointers in place of set 0's host-built ones
         std::string serr;
-        rc = ismpc::sweep_build(params, K, h->t, c.midx, c.midy, c.e_lo, c.ne, 16, quad_R(t.p.N, 16), h->own_stream, h->sw, h->dev_allocs, serr);
+        // 8 lanes per instance beyond LPI16_BATCH, as plain handles take them, is opt-in here (ISMPC_LPI=8): with eight instances of a
+        // wavefront reading eight sets' tables it measured level to 2 % slower on the 64-set batch (9.25-9.28 against 9.27-9.43e8 ticks/s)
+        const char* lp8 = std::getenv("ISMPC_LPI");
+        const bool lanes8 = lp8 && std::atoi(lp8) == 8;
+        rc = ismpc::sweep_build(params, K, h->t, c.midx, c.midy, c.e_lo, c.ne, 16, quad_R(t.p.N, 16), lanes8 ? 8 : 0, quad_R(t.p.N, 8), h->own_stream, h->sw, h->dev_allocs, serr);
         if (rc != ISMPC_OK) { ismpc_destroy(h); return fail(rc, serr); }
         std::vector<DevConst> cs((size_t)K, h->c);
         for (int k = 0; k < K; ++k) {
@@ -2267,6 +2296,14 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
         h->dev_allocs.push_back(sp);
         if (hipMemcpy(sp, cs.data(), sizeof(DevConst) * (size_t)K, hipMemcpyHostToDevice) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_NO_DEVICE, "sweep: set records upload failed"); }
         h->c.sets = static_cast<const DevConst*>(sp); h->c.nsets = K;
+        if (h->sw.vqT2) {                                      // the same records over the 8-lane copy of the affine tables (pick_layout)
+            for (int k = 0; k < K; ++k) cs[k].vqT = h->sw.vqT2 + (size_t)k * h->sw.s_vqT2;
+            void* sp8 = nullptr;
+            if (hipMalloc(&sp8, sizeof(DevConst) * (size_t)K) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_ALLOC, "sweep: set records allocation failed"); }
+            h->dev_allocs.push_back(sp8);
+            if (hipMemcpy(sp8, cs.data(), sizeof(DevConst) * (size_t)K, hipMemcpyHostToDevice) != hipSuccess) { ismpc_destroy(h); return fail(ISMPC_E_NO_DEVICE, "sweep: set records upload failed"); }
+            h->sets8 = static_cast<const DevConst*>(sp8);
+        }
     }
     {
         void* cp = nullptr;
@@ -2328,15 +2365,16 @@ int ismpc_sweep_verify_tables(ismpc_handle* h, int set, double* rel_err)
     rel_err[5] = rel(d, t.SHSt);
     { std::vector<double> dx, dy; if (!fetch(S.tailx + (size_t)set * S.s_tail, S.s_tail, dx) || !fetch(S.taily + (size_t)set * S.s_tail, S.s_tail, dy)) return fail(ISMPC_E_NO_DEVICE, "download failed");
       rel_err[6] = std::max(rel(dx, t.tailx), rel(dy, t.taily)); }
-    {   // the lane-group layout, against the host's re-striding of ITS vtab
-        const int R = quad_R(N, 16), lpi = 16; const size_t npp = (size_t)t.npat + 1;
+    rel_err[7] = 0.0;
+    for (int pass = 0; pass < (S.vqT2 ? 2 : 1); ++pass) {   // the lane-group layouts (16 lanes, 8 lanes), against the host's re-striding of ITS vtab
+        const int lpi = pass == 0 ? 16 : 8, R = quad_R(N, lpi); const size_t npp = (size_t)t.npat + 1;
         hv.assign(npp * R * 3 * lpi * 2, 0.0);
         for (size_t pp = 0; pp < npp; ++pp) for (int r = 0; r < R; ++r) for (int k = 0; k < 3; ++k) for (int li = 0; li < lpi; ++li) {
             const int n = li * R + r; const size_t dst = (((pp * R + r) * 3 + k) * lpi + li) * 2;
             hv[dst] = t.vtab[(pp * 6 + 2 * k) * NTq + n]; hv[dst + 1] = t.vtab[(pp * 6 + 2 * k + 1) * NTq + n];
         }
-        if (!fetch(S.vqT + (size_t)set * S.s_vqT, S.s_vqT, d)) return fail(ISMPC_E_NO_DEVICE, "download failed");
-        rel_err[7] = rel(d, hv);
+        if (!fetch(pass == 0 ? S.vqT + (size_t)set * S.s_vqT : S.vqT2 + (size_t)set * S.s_vqT2, pass == 0 ? S.s_vqT : S.s_vqT2, d)) return fail(ISMPC_E_NO_DEVICE, "download failed");
+        rel_err[7] = std::max(rel_err[7], rel(d, hv));
     }
     return ISMPC_OK;
 }
@@ -2457,10 +2495,10 @@ int ismpc_rollout_device(ismpc_handle* h, int batch, ismpc_tick_in* state_dev, i
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
     if (batch > 0 && ticks > 0 && h->kernel_rollout && !h->dense_path && h->quad_path && h->c.N <= 128 && h->z_fallback) {
         // the whole closed loop in ONE launch: state in registers, one trajectory record per tick (ismpc_rollout_quad)
-        const bool small = h->lpi_auto && h->vqT32 && batch <= LPI32_BATCH;
-        const int lpi = small ? 32 : h->lpi, RQ = quad_R(h->c.N, lpi);
+        const LaneLayout lay = pick_layout(h, batch, false);
+        const int lpi = lay.lpi, RQ = quad_R(h->c.N, lpi);
         DevConst cq = h->c;
-        if (small) { cq.vqT = h->vqT32; cq.tzgT = h->tzgT32; }
+        cq.vqT = lay.vqT; cq.tzgT = lay.tzgT;
         const int waves = (batch * lpi + 63) / 64;
         const dim3 qgrid((waves + ISMPC_QUAD_WAVES - 1) / ISMPC_QUAD_WAVES), qblock(64 * ISMPC_QUAD_WAVES);
         if (batch > h->zstop_cap) {                       // stream-ordered growth, as zmark (ismpc_reserve sizes it beforehand)

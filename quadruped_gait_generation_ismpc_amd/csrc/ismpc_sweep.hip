@@ -345,7 +345,7 @@ int dalloc(double** p, size_t n, std::vector<void*>& allocs, std::string& err)
 }  // namespace
 
 int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double* midx_dev, const double* midy_dev, const int* e_lo_dev,
-                const int* ne_dev, int lpi, int R, hipStream_t s, SweepSlabs& o, std::vector<void*>& allocs, std::string& err)
+                const int* ne_dev, int lpi, int R, int lpi2, int R2, hipStream_t s, SweepSlabs& o, std::vector<void*>& allocs, std::string& err)
 {
     const int N = t0.p.N;
     if (K < 1) { err = "a sweep needs at least one parameter set"; return ISMPC_E_INVALID; }
@@ -356,6 +356,7 @@ int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double*
     const double dt = t0.p.mpc_dt;
     o.K = K; o.NG = NG;
     o.s_mat = (size_t)NG * NG; o.s_vtab = (size_t)(t0.npat + 1) * 6 * NT; o.s_vqT = (size_t)(t0.npat + 1) * R * 3 * lpi * 2;
+    o.s_vqT2 = lpi2 > 0 ? (size_t)(t0.npat + 1) * R2 * 3 * lpi2 * 2 : 0;
     o.s_W = (size_t)t0.npat * t0.Fmax * NT; o.s_HS = (size_t)N * NT; o.s_tail = (size_t)t0.nmid;
     // per-set scalars; the Newton start 1 / bound(|H|_inf) and the iteration count from cond(H) <= bound / min(q_u, 1)
     std::vector<double> par((size_t)K * PAR);
@@ -378,7 +379,8 @@ int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double*
     if ((rc = dalloc(&o.U, o.s_mat, allocs, err)) || (rc = dalloc(&o.Ut, o.s_mat, allocs, err))) return rc;
     if ((rc = dalloc(&o.hvec, (size_t)K * 3 * NG, allocs, err))) return rc;
     if ((rc = dalloc(&o.vtab, (size_t)K * o.s_vtab, allocs, err)) ||
-        (rc = dalloc(&o.vqT, (size_t)K * o.s_vqT, allocs, err)) || (rc = dalloc(&o.Wt, (size_t)K * o.s_W, allocs, err)) ||
+        (rc = dalloc(&o.vqT, (size_t)K * o.s_vqT, allocs, err)) || (lpi2 > 0 && (rc = dalloc(&o.vqT2, (size_t)K * o.s_vqT2, allocs, err))) ||
+        (rc = dalloc(&o.Wt, (size_t)K * o.s_W, allocs, err)) ||
         (rc = dalloc(&o.SW, (size_t)K * o.s_W, allocs, err)) || (rc = dalloc(&o.HSt, (size_t)K * o.s_HS, allocs, err)) ||
         (rc = dalloc(&o.SHSt, (size_t)K * o.s_HS, allocs, err)) || (rc = dalloc(&o.tailx, (size_t)K * o.s_tail, allocs, err)) ||
         (rc = dalloc(&o.taily, (size_t)K * o.s_tail, allocs, err))) return rc;
@@ -417,6 +419,7 @@ int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double*
     hipLaunchKernelGGL(sweep_patterns, dim3(t0.npat + 1, K), dim3(256), 0, s, (const double*)o.par, (const double*)o.X0, o.s_mat, (const double*)o.hvec,
                        e_lo_dev, ne_dev, t0.npat, t0.Fmax, o.vtab, o.s_vtab, o.Wt, o.SW, o.s_W, N, NG, dt);
     hipLaunchKernelGGL(sweep_layout, dim3(t0.npat + 1, K), dim3(256), 0, s, (const double*)o.vtab, o.s_vtab, o.vqT, o.s_vqT, lpi, R);
+    if (lpi2 > 0) hipLaunchKernelGGL(sweep_layout, dim3(t0.npat + 1, K), dim3(256), 0, s, (const double*)o.vtab, o.s_vtab, o.vqT2, o.s_vqT2, lpi2, R2);
     hipLaunchKernelGGL(sweep_tail, dim3((t0.nmid + 255) / 256, K), dim3(256), 0, s, (const double*)o.par, midx_dev, midy_dev, t0.nmid, o.tailx, o.taily, o.s_tail, N, dt);
     SW_TRY(hipGetLastError());
     SW_TRY(hipEventRecord(e1, s));

@@ -28,6 +28,7 @@ struct SweepSlabs {                 // one device slab per table kind, set k at 
     double *U = nullptr, *Ut = nullptr;   // m S' and m S (common to the sets: unit mass), NG x NG
     double *hvec = nullptr;         // 3 x NG per set: Hinv f0, Hinv fa, Hinv fb
     double *vtab = nullptr, *vqT = nullptr, *Wt = nullptr, *SW = nullptr, *HSt = nullptr, *SHSt = nullptr, *tailx = nullptr, *taily = nullptr;
+    double* vqT2 = nullptr; size_t s_vqT2 = 0;   // the second lane-group layout of vtab (lpi2 / R2; null without one)
     size_t s_mat = 0, s_vtab = 0, s_vqT = 0, s_W = 0, s_HS = 0, s_tail = 0;   // strides (doubles)
     double* par = nullptr;          // K x 8: mass, q_p, q_u, q_v, h_des, eta, 1 / bound(|H|_inf), g
     int newton_iters = 0, gemm_launches = 0;
@@ -36,8 +37,9 @@ struct SweepSlabs {                 // one device slab per table kind, set k at 
 };
 
 // Builds every per-set table on `stream` (synchronises before returning).  `t0` = host tables of set 0 (plan, patterns, structure).
-// lpi / R: lane-group layout of vqT (ismpc_hip.hip quad_R).  All device memory is appended to `allocs`.
+// lpi / R: lane-group layout of vqT (ismpc_hip.hip quad_R); lpi2 / R2: a second layout beside it (vqT2; lpi2 = 0: none).  All device
+// memory is appended to `allocs`.
 int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double* midx_dev, const double* midy_dev, const int* e_lo_dev,
-                const int* ne_dev, int lpi, int R, hipStream_t stream, SweepSlabs& out, std::vector<void*>& allocs, std::string& err);
+                const int* ne_dev, int lpi, int R, int lpi2, int R2, hipStream_t stream, SweepSlabs& out, std::vector<void*>& allocs, std::string& err);
 
 }  // namespace ismpc

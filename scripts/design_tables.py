@@ -33,7 +33,7 @@ def fmt(x, nd=2):
 
 LEGS = [("headline_b65536", "B, 65 536 instances (configs[2], the bench line)", "ismpc_tick_quad_one<"),
         ("shard_b32768", "B, 32 768 instances (configs[2] per-GPU shard at N = 2)", "ismpc_tick_quad_one<"),
-        ("shard_b16384", "B, 16 384 instances (configs[2] per-GPU shard at N = 4)", "ismpc_tick_quad_one<"),
+        ("shard_b16384", "B, 16 384 instances (configs[2] per-GPU shard at N = 4)", "ismpc_tick_quad_inline<"),
         ("shard_b8192", "B, 8 192 instances (configs[2] per-GPU shard at N = 8)", "ismpc_tick_quad_inline<"),
         ("config1_b1024", "B, 1 024 instances (configs[1])", "ismpc_tick_quad_inline<"),
         ("sweep_k64_b65536", "B, 65 536 instances, 64 parameter sets (sweep)", "ismpc_tick_quad<"),

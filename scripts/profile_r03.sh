@@ -16,7 +16,7 @@ for spec in $LEGS; do
   case $leg in
     headline)      key=headline_b65536; kern='ismpc_tick_quad_one<'; batch=65536; steps=40 ;;
     shard_b8192)   key=shard_b8192;     kern='ismpc_tick_quad_inline<'; batch=8192;  steps=40 ;;
-    shard_b16384)  key=shard_b16384;    kern='ismpc_tick_quad_one<'; batch=16384; steps=40 ;;
+    shard_b16384)  key=shard_b16384;    kern='ismpc_tick_quad_inline<'; batch=16384; steps=40 ;;
     shard_b32768)  key=shard_b32768;    kern='ismpc_tick_quad_one<'; batch=32768; steps=40 ;;
     config1_b1024) key=config1_b1024;   kern='ismpc_tick_quad_inline<'; batch=1024;  steps=40 ;;
     sweep_k64_b65536) key=sweep_k64_b65536; kern='ismpc_tick_quad<'; batch=65536; steps=40 ;;      # + the MFMA table build: pmc_sweep_gemm.json below

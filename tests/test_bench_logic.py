@@ -61,16 +61,17 @@ def test_kernel_names_and_credits_follow_the_launch_rules(bench, monkeypatch):
     b, _ = bench
     for k in ("ISMPC_PATH", "ISMPC_LPI", "ISMPC_ONE_LAUNCH", "ISMPC_Z_FALLBACK"):
         monkeypatch.delenv(k, raising=False)
-    assert b.kernel_name_b(100, 65536, 256) == "ismpc_tick_quad_one<7, 16, 2, false>"     # > 8 wavefronts per CU: one launch at three wavefronts per SIMD
+    assert b.kernel_name_b(100, 65536, 256) == "ismpc_tick_quad_one<13, 8, 2, false>"     # > 8 wavefronts per CU: one launch at the tick's own residency; 8 lanes per instance beyond 8 192
+    assert b.kernel_name_b(100, 16384, 256) == "ismpc_tick_quad_inline<13, 8, 2>"         # eight instances per wavefront: 16 384 are resident at once
     assert b.kernel_name_b(100, 65536, 256, sweep=True) == "ismpc_tick_quad_one<7, 16, 2, true>"
     assert b.kernel_name_b(100, 65536, 256, sweep=True, deferring=True) == "ismpc_tick_quad<7, 16, true>"   # ... two while instances are deferred
-    assert b.kernel_name_b(100, 65536, 256, deferring=True) == "ismpc_tick_quad<7, 16, false>"
+    assert b.kernel_name_b(100, 65536, 256, deferring=True) == "ismpc_tick_quad<13, 8, false>"
     assert b.kernel_name_b(100, 8192, 256, deferring=True) == "ismpc_tick_quad_inline<7, 16, 2>"
     monkeypatch.setenv("ISMPC_ONE_LAUNCH", "0")
-    assert b.kernel_name_b(100, 65536, 256) == "ismpc_tick_quad<7, 16, false>"       # A/B: the two-launch form
+    assert b.kernel_name_b(100, 65536, 256) == "ismpc_tick_quad<13, 8, false>"       # A/B: the two-launch form
     assert b.kernel_name_b(100, 8192, 256) == "ismpc_tick_quad<7, 16, false>"
     monkeypatch.setenv("ISMPC_ONE_LAUNCH", "1")
-    assert b.kernel_name_b(100, 65536, 256) == "ismpc_tick_quad<7, 16, false>"       # A/B: one launch only for resident batches (rounds 2-3)
+    assert b.kernel_name_b(100, 65536, 256) == "ismpc_tick_quad<13, 8, false>"       # A/B: one launch only for resident batches (rounds 2-3)
     monkeypatch.delenv("ISMPC_ONE_LAUNCH")
     assert b.kernel_name_b(100, 8192, 256) == "ismpc_tick_quad_inline<7, 16, 2>"     # every wavefront resident: one launch
     assert b.kernel_name_b(100, 1024, 256) == "ismpc_tick_quad_inline<4, 32, 2>"     # <= 2 048 instances: 32 lanes per instance

@@ -48,13 +48,13 @@ def test_device_built_tables_match_the_long_double_host_build(q, sweep64):
     assert worst["SW"] <= 1e-11, worst                                 # S W_p inherits W_p's error through N^2 / 2-term sums (parity needs 1e-6)
 
 
-def test_sweep_batch_against_one_oracle_per_set(q, sweep64):
-    """4 096 instances, instance i runs with parameter set i % 64; the oracle (fresh tables per set, reference qpOASES where
-    built) solves a sample of every set."""
+@pytest.mark.parametrize("B", [4096, 12288])
+def test_sweep_batch_against_one_oracle_per_set(q, sweep64, B):
+    """Instance i runs with parameter set i % 64; the oracle (fresh tables per set, reference qpOASES where built) solves a sample of
+    every set."""
     from oracle import oracle as O
     from quadruped_gait_generation_ismpc_amd import workload
     s, ps = sweep64
-    B = 4096
     tin = workload.make_batch(100, B, seed=13)
     tin["reserved"] = np.arange(B) % 64
     out = s.solve_batch(tin)
@@ -81,6 +81,25 @@ def test_sweep_batch_against_one_oracle_per_set(q, sweep64):
     o2 = s.solve_batch(t2)
     run = ((out["status"] | o2["status"]) & (q.ST_ERROR_MASK | q.ST_FLIGHT | q.ST_TICK_SKIPPED)) == 0
     assert (np.abs(out["u0"][run, 0] - o2["u0"][run, 0]) > 1e-3).mean() > 0.9
+
+
+def test_sweep_with_eight_lanes_per_instance(q, sweep64, monkeypatch):
+    """ISMPC_LPI=8: beyond 8 192 instances per launch a sweep handle runs eight instances per wavefront over the 8-lane copy of every
+    set's tables (opt-in: measured no faster than 16 lanes when the instances of a wavefront use different sets).  Same records as the
+    default handle up to summation order; the device-built 8-lane layout is checked against the host's."""
+    from quadruped_gait_generation_ismpc_amd import workload
+    s16, ps = sweep64
+    monkeypatch.setenv("ISMPC_LPI", "8")
+    s8 = q.MPCSolver.sweep(q.reference_plan(params=ps[0]), ps)
+    assert max(s8.sweep_verify_tables(k)["layout"] for k in (0, 17, 63)) <= 1e-12
+    tin = workload.make_batch(100, 12288, seed=14)
+    tin["reserved"] = np.arange(len(tin)) % 64
+    a, b = s16.solve_batch(tin), s8.solve_batch(tin)
+    ok = ((a["status"] | b["status"]) & q.ST_ERROR_MASK) == 0
+    assert ok.mean() > 0.95 and np.array_equal(a["status"][ok], b["status"][ok])
+    assert np.abs(a["com_pos"] - b["com_pos"])[ok].max() <= 1e-11 and np.abs(a["com_vel"] - b["com_vel"])[ok].max() <= 1e-10
+    assert (np.abs(a["u0"] - b["u0"])[ok] <= 1e-9 * np.maximum(np.abs(a["u0"][ok]), 1.0)).all()
+    s8.close()
 
 
 def test_sweep_of_equal_sets_is_the_plain_handle(q):
