@@ -1726,7 +1726,10 @@ void ismpc_tick_quad_inline(const DevConst c, const ismpc_tick_in* __restrict__ 
 // 65 536 instances, +4 % at 32 768, +8 % at 16 384 (same box, scripts/ab_env.sh ISMPC_ONE_LAUNCH=0).  SW: parameter sweeps, the
 // fallback runs on the deferred instance's own set.
 // wavefronts per SIMD of ismpc_tick_quad<R, LPI, SW> (profiles/r03/kernel_resources.md): what the one-launch form asks for
-template <int R, bool SW> constexpr int one_occ() { return R <= 4 ? (SW ? 3 : 4) : R <= 7 ? 3 : R == 8 ? (SW ? 2 : 3) : R <= 13 ? 2 : 1; }
+#ifndef ISMPC_OCC_R13
+#define ISMPC_OCC_R13 2
+#endif
+template <int R, bool SW> constexpr int one_occ() { return R <= 4 ? (SW ? 3 : 4) : R <= 7 ? 3 : R == 8 ? (SW ? 2 : 3) : R <= 13 ? ISMPC_OCC_R13 : 1; }
 template <int RW, int OCC>        // OCC: one copy per residency target (the register budget comes down from the calling kernels)
 __device__ __attribute__((noinline))
 void fallback_call_one(const DevConst* cp, int gi, int lane, const ismpc_tick_in* in_ro, ismpc_tick_in* state_rw,
