@@ -600,8 +600,7 @@ template <int R>
 __device__ __forceinline__ void z_project(const DevConst& c, int n0, int pat, int elo, int ne, double uel, double (&pc)[R], double (&gc)[R])
 {
     constexpr int NT = ismpc::Tables::NT;
-#pragma unroll 4
-    for (int e = 0; e < ne; ++e) {
+    for (int e = 0; e < ne; ++e) {                       // (not unrolled: the lane read is a convergent operation)
         const double ue = readlane_dyn(uel, e);
         double wv[R], sv[R];
         loadR<R>(c.Wt + ((size_t)pat * c.Fmax + e) * NT + n0, wv); loadR<R>(c.SW + ((size_t)pat * c.Fmax + e) * NT + n0, sv);
