@@ -167,7 +167,12 @@ int ismpc_host_unregister(void* p);
  * inequality fallback): launches of ONE handle must be ordered -- one stream, or
  * streams synchronised by the caller.  Independent handles are independent.
  * When that scratch has to grow inside a call whose stream is not the previous
- * call's, the previous stream is drained first (ismpc_reserve avoids both).   */
+ * call's, the previous stream is drained first (ismpc_reserve avoids both).
+ * Reproducibility: an instance's record does not depend on where it sits in the
+ * batch nor on the other instances, byte for byte, as long as the batch stays in
+ * one size class (<= 2 048, <= 8 192, larger: the kernels use 32, 16 and 8 lanes
+ * per instance, which sum in different orders); across classes records agree to
+ * rounding (~1e-15 relative).  ISMPC_LPI=8|16|32 fixes one layout for all sizes. */
 int ismpc_solve_batch_device(ismpc_handle* h, int batch,
                              const ismpc_tick_in* in_dev, ismpc_tick_out* out_dev,
                              double* u_traj, void* stream);
