@@ -40,15 +40,17 @@ if ROOT not in sys.path:
 
 # VALU peaks the executed flops are priced against (MI355X_MICROARCH.md / AMD spec): FP64 vector = matrix 78.6 TFLOP/s (1024 SIMDs x
 # 16 lanes x 2 flop x 2.4 GHz: one wave64 v_fma_f64 per 4 cycles), FP32 vector 157.3 TFLOP/s (one wave64 v_fma_f32 per 2 cycles).
-# Measured on the box with scripts/micro/valu_peak.hip (profiles/r03/valu_peak.json): v_fma_f64 69.3, UNPACKED v_fma_f32 123.1,
+# Measured on the box with scripts/micro/valu_peak.hip (profiles/r04/valu_peak.json): v_fma_f64 69.3, UNPACKED v_fma_f32 123.1,
 # v_pk_fma_f32 146.0 TFLOP/s -- the fp32 solve issues unpacked instructions (the library is built -fno-slp-vectorize) and they do run
 # at the two-cycle rate.  A kernel that executes both types is priced against the blend: peak = flops / (f64/78.6 + f32/157.3).
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}
 PEAK_NOTE = ("FP64 vector (= matrix) 78.6 TFLOP/s, FP32 vector 157.3 TFLOP/s; a kernel executing both is priced against the blend flops / (f64 / 78.6 + "
-             "f32 / 157.3).  Measured FMA rates on the box (profiles/r03/valu_peak.json): v_fma_f64 69.3, unpacked v_fma_f32 123.1, v_pk_fma_f32 146.0 TFLOP/s")
+             "f32 / 157.3).  Measured FMA rates on the box (profiles/r04/valu_peak.json): v_fma_f64 69.3, unpacked v_fma_f32 123.1, v_pk_fma_f32 146.0 TFLOP/s")
 CLOCK_GHZ = 2.4              # MI355X_MICROARCH.md "Max clock"
 SIMDS = 256 * 4
-PROFILES = os.path.join(ROOT, "profiles", "r03")
+PROFILES = os.path.join(ROOT, "profiles", "r04")
+LINE_LIMIT = 6000            # bytes of the ONE JSON line (the driver keeps an 8 KB tail of stdout: round 3's 27 KB line was never parsed)
+DETAIL_NAME = "bench_detail.json"   # every leg's full object (prose notes, counters, host-path statistics), written next to bench.py
 GLOBAL_BATCH = 65536
 HORIZON = 100
 A_BATCH = 16384
@@ -70,14 +72,14 @@ def cpu_worker(spec):
         from oracle import oracle as O
         N = int(spec.get("horizon", HORIZON))
         tin = workload.make_batch(N, n, first_instance=off)
-        orc = O.Oracle(O.default_params(N), backend="ref" if O.have_ref() else "gi")
+        orc = O.Oracle(O.default_params(N), backend=spec.get("backend") or ("ref" if O.have_ref() else "gi"))
         orc.solve(tin[:2])
         t0 = time.perf_counter(); orc.solve(tin); dt = time.perf_counter() - t0
         done = n
     elif leg.startswith("A:"):
         from oracle import oracle_a as A
         name = leg[2:]
-        backend = "ref" if A.O.have_ref() else "gi"
+        backend = spec.get("backend") or ("ref" if A.O.have_ref() else "gi")
         if name == "mc_C200":
             inst, push = workload.make_inst_mc(off + n)
             phi, dA = np.pi / 4, 0.1
@@ -155,7 +157,12 @@ def cpu_baseline(leg, unit, budget_s, sample_desc, unit_per_n=1, horizon=HORIZON
     allc = _collect([_spawn_worker(dict(leg=leg, n=n1, offset=0, cpu=c, horizon=horizon)) for c in share], 1800)
     multi = sum(r["n"] / r["seconds"] for r in allc)
     qp = "reference vendored qpOASES 3.2 (setToMPC, nWSR=300, cold init per QP)" if kind == "reference" else "oracle Goldfarb-Idnani"
-    return {"value": single, "unit": unit, "cores": 1, "kind": kind,
+    own = None
+    if kind == "reference":
+        # the build's own CPU restatement (oracle + its Goldfarb-Idnani QP) beside (ii) the reference's qpOASES
+        o = _collect([_spawn_worker(dict(leg=leg, n=n1, offset=0, cpu=share[0], horizon=horizon, backend="gi"))], 900)[0]
+        own = {"value": o["n"] / o["seconds"], "cores": 1, "kind": "port", "sample": f"{o['n']} {unit.split('/')[0]} in {o['seconds']:.1f} s, oracle with its own dense Goldfarb-Idnani QP"}
+    return {"value": single, "unit": unit, "cores": 1, "kind": kind, "own": own,
             "sample": f"{sample_desc}: {one['n']} {unit.split('/')[0]} in {one['seconds']:.1f} s on one pinned core, {qp}",
             "ms_per_unit": 1e3 / single,
             "all_cores": {"value": multi, "cores": len(share),
@@ -220,7 +227,12 @@ def spawn_ranks(n, argv, timeout_s=3000):
 
 
 class Ranks:
-    def __init__(self, gpus, force_collective=False):
+    """The launcher's view: rank / world from the environment, the device, and the CONTROL plane (barrier, max over ranks, the 128-byte
+    RCCL unique id).  collective = "abi" (default): the data plane is the native library's own RCCL communicator (include/ismpc_group.h,
+    ismpc_group_create_rank) and torch.distributed runs over gloo for the control plane only; "torch": torch.distributed's nccl backend
+    (= RCCL) carries both (round 3's path, kept for A/B)."""
+
+    def __init__(self, gpus, force_collective=False, collective="abi"):
         import torch
         self.torch = torch
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -241,13 +253,14 @@ class Ranks:
         # force_collective: a ONE-rank RCCL group, so that the path's collective (communicator set-up, the side-stream
         # all-gather and its event order) runs on a one-GPU box too -- over a group of one rank it moves no bytes between GPUs
         self.collective = self.world > 1 or force_collective
+        self.abi = collective == "abi"
         if self.collective:
             import torch.distributed as dist
             self.dist = dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if "MASTER_PORT" not in os.environ:
                 os.environ["MASTER_PORT"] = str(_free_port())
-            if self.rehearse:
+            if self.rehearse or self.abi:
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             else:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)   # "nccl" is RCCL on ROCm
@@ -259,9 +272,17 @@ class Ranks:
     def max(self, x):
         if self.world == 1:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=("cpu" if self.rehearse else self.dev))
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=("cpu" if (self.rehearse or self.abi) else self.dev))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def unique_id(self):
+        """The communicator's 128 bytes: made by rank 0 (ismpc_group_unique_id), handed to every rank over the control plane."""
+        from quadruped_gait_generation_ismpc_amd import group as G
+        box = [G.unique_id() if self.rank == 0 else None]
+        if self.world > 1:
+            self.dist.broadcast_object_list(box, src=0)
+        return box[0]
 
     def close(self):
         if self.dist is not None:
@@ -313,7 +334,7 @@ class RegionEvents:
 
 
 def load_pmc(leg):
-    """profiles/r03/pmc_<leg>.json (scripts/profile_r03.sh + scripts/pmc_summary.py): counters of the dominant kernel,
+    """profiles/r04/pmc_<leg>.json (scripts/profile_r04.sh + scripts/pmc_summary.py): counters of the dominant kernel,
     mean per launch, collected on exactly this leg's batch -- never scaled from another batch."""
     base = os.environ.get("ISMPC_PROFILES_DIR") or PROFILES
     path = os.path.join(base, f"pmc_{leg}.json")
@@ -327,10 +348,33 @@ def load_pmc(leg):
         return None
 
 
+_LIB_SHA = {}
+
+
+def lib_sha256(path=None):
+    """sha256 of the HIP library the process loads (quadruped_gait_generation_ismpc_amd/libismpc_hip.so, or $ISMPC_LIB): what ties a committed
+    counter summary to the binary it was collected from (scripts/pmc_summary.py writes the same hash into every pmc_*.json; the hipcc
+    build is reproducible: the same sources give the same bytes)."""
+    import hashlib
+    if path is None:
+        from quadruped_gait_generation_ismpc_amd import _lib
+        path = _lib.LIB_PATH
+    if path not in _LIB_SHA:
+        try:
+            h = hashlib.sha256()
+            with open(path, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 20), b""):
+                    h.update(blk)
+            _LIB_SHA[path] = h.hexdigest()
+        except OSError:
+            _LIB_SHA[path] = None
+    return _LIB_SHA[path]
+
+
 def roofline(leg, kernel, kernel_ms, batch, dtype, alg_flops, alg_bytes, extra=None, note=""):
     """The contract's roofline object for one leg.  `achieved` / `frac` are a MEASUREMENT of what the kernel executes: the
     floating-point wave-instructions the SQ counted for this kernel on this batch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_{F64,F32},
-    committed under profiles/r03/) x 64 lanes, FMA = 2 flop, over the kernel's own launch duration (HIP events, live), against
+    committed under profiles/r04/) x 64 lanes, FMA = 2 flop, over the kernel's own launch duration (HIP events, live), against
     the VALU peak of the arithmetic type.  The SURVEY 8d figure (a dense solve the kernels do not run) is kept beside it as
     `algorithmic_credit` and carries no fraction.  `issue` is the time the vector pipes spend issuing ALL VALU instructions
     (4 cycles per wave64 instruction per SIMD) over the same duration -- also <= 1 by construction."""
@@ -344,12 +388,18 @@ def roofline(leg, kernel, kernel_ms, batch, dtype, alg_flops, alg_bytes, extra=N
     if extra:
         rf.update(extra)
     if not j or j.get("batch") != batch or j.get("kernel", "") not in kernel:
-        rf["note"] += "  (no PMC summary for this leg / batch under profiles/r03: achieved, frac, traffic left null)"
+        rf["note"] += "  (no PMC summary for this leg / batch under profiles/r04: achieved, frac, traffic left null)"
+        return rf
+    sha = lib_sha256()
+    rf["lib_sha256"] = sha; rf["pmc_lib_sha256"] = j.get("lib_sha256"); rf["pmc_git_head"] = j.get("git_head")
+    if sha is None or j.get("lib_sha256") != sha:
+        # the counters were collected from another build of the library than the one loaded now: no executed-work figure is derived from them
+        rf["note"] += "  (STALE PMC summary: its lib_sha256 is not the loaded library's; achieved, frac, traffic left null -- rerun scripts/profile_r04.sh)"
         return rf
     c, d = j.get("counters_mean_per_launch", {}), j.get("derived", {})
     per_step = float(j.get("launches_per_step", 1))
     fl64, fl32 = d.get("flops_f64_per_launch"), d.get("flops_f32_per_launch")
-    ex = {"source": "profiles/r03/pmc_" + str(j.get("leg", leg)) + ".json"}
+    ex = {"source": "profiles/r04/pmc_" + str(j.get("leg", leg)) + ".json"}
     if fl64 is not None and fl32 is not None and fl64 + fl32 > 0:
         flops = (fl64 + fl32) * per_step
         rf["achieved"] = flops / (kernel_ms * 1e-3) / 1e12
@@ -477,12 +527,22 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
     d_in = q.to_device(tick_in, R.dev)
     d_out = [torch.empty((B, 80), dtype=torch.uint8, device=R.dev) for _ in range(2)]
     cus = torch.cuda.get_device_properties(R.dev).multi_processor_count
-    pipe = None
-    if R.collective:
+    pipe, grp = None, None
+    if R.collective and R.abi and not R.rehearse and sweep_sets == 0:
+        # the product's multi-GPU path: one native group per rank (its own handle, launch stream, side stream, RCCL communicator); the
+        # shard's kernel writes into the gathered buffer in place and ONE ncclAllGather completes it on every GPU (csrc/ismpc_group.hip)
+        from quadruped_gait_generation_ismpc_amd import group as G
+        grp = G.Group.from_rank(q.reference_plan(params=p), p, R.local_rank, R.unique_id(), rank, world)
+        assert grp.world == world and grp.shard(global_batch) == (first, B)
+        grp.reserve(global_batch)
+        torch.cuda.synchronize()                                         # d_in is complete before the group's own streams read it
+    elif R.collective:
         pipe = GatherPipeline(world, B, 80, device=("cpu" if R.rehearse else R.dev), host_copies=R.rehearse)
 
     def step(k):
-        if pipe is None:
+        if grp is not None:
+            grp.step_device(global_batch, [d_in.data_ptr()], k & 1)
+        elif pipe is None:
             solver.solve_batch_torch(d_in, d_out[0])
         else:
             b = pipe.before_launch(k)                                    # gather k-2 has left d_out[b]
@@ -490,9 +550,11 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
             pipe.after_launch(k, d_out[b])                               # the one collective of the path, on the side stream
 
     ev = RegionEvents(torch)
-    walls = timed_regions(R, step, K, W, min_ms, drain=(pipe.drain if pipe else None), ev=(ev.start, ev.end))
+    walls = timed_regions(R, step, K, W, min_ms, drain=(grp.sync if grp else (pipe.drain if pipe else None)), ev=(ev.start, ev.end))
     wall = statistics.median(walls)
-    step_interval_ms = ev.median_ms(K)
+    step_interval_ms = ev.median_ms(K) if grp is None else 1e3 * wall / K      # (the group launches on its own streams: events on torch's stream do not see them)
+    if grp is not None:
+        solver.solve_batch_torch(d_in, d_out[0])                         # this rank's shard through the plain handle: what the gathered buffer must hold at [first, first + B)
 
     # ---- dominant kernel alone (roofline): same inputs.  Two durations: a train of K back-to-back launches (per-launch
     # interval, event pair per region) and ONE launch between synchronisations (what rocprofv3 reports per dispatch)
@@ -512,12 +574,19 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
     kernel_ms_train = ev2.median_ms(K)
     kernel_ms = isolated_ms(torch, lambda: solo.solve_batch_torch(d_in, d_tmp))
     collective_ms = None
+    if grp is not None:
+        # the collective alone: steps whose kernels are already done do not exist in this API, so time a train of full steps against the
+        # kernel train measured above -- the difference is what the all-gather adds when it does NOT hide behind the next kernel
+        collective_ms = max(0.0, 1e3 * wall / K - kernel_ms_train)
     if pipe is not None:
         ev3 = RegionEvents(torch)
         timed_regions(R, lambda k: pipe.gather_blocking(d_out[0]), K, W, min_ms, ev=(ev3.start, ev3.end))
         collective_ms = ev3.median_ms(K) if not R.rehearse else None
 
     out = q.from_device(d_out[0], q.TICK_OUT)
+    if grp is not None:
+        allout = q.from_device(grp.result_torch(global_batch, 0, (K - 1) & 1).clone(), q.TICK_OUT)
+        assert allout[first:first + B].tobytes() == out.tobytes(), "group all-gather misplaced or altered this rank's shard"
     if pipe is not None:
         allout = pipe.result_numpy((K - 1) & 1, q.TICK_OUT)
         assert allout[rank * B:(rank + 1) * B].tobytes() == q.from_device(d_out[(K - 1) & 1], q.TICK_OUT).tobytes(), "all-gather misplaced this rank's shard"
@@ -540,7 +609,8 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
                                    f"global batch {global_batch} ({B} instances/GPU), nominal pre-roll + perturbation (SURVEY 8d)",
                        "horizon": N, "global_batch": global_batch, "batch_per_gpu": B,
                        "collective": (f"one RCCL all-gather of 80-byte output records per step over {world} rank(s), side stream, double-buffered "
-                                      "(overlaps the next step's kernel)") if pipe is not None else "none (1 GPU)",
+                                      "(overlaps the next step's kernel); " + ("issued by the native library (ismpc_group_step_device, ncclAllGather in place)" if grp is not None
+                                                                               else "issued through torch.distributed")) if (pipe is not None or grp is not None) else "none (1 GPU)",
                        "flight_fraction": float(((st & q.ST_FLIGHT) != 0).mean()),
                        "infeasible_fraction": float(((st & (q.ST_X_INFEASIBLE | q.ST_Y_INFEASIBLE)) != 0).mean()),
                        "z_inequality_active_fraction": float(((st & q.ST_Z_INEQ_ACTIVE) != 0).mean()),
@@ -548,14 +618,19 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
             "roofline": roofline(leg, kname, kernel_ms, B, "f64", flops, 152.0 * B,
                                  extra={"kernel_ms_train": kernel_ms_train, "step_interval_ms": step_interval_ms},
                                  note="kernel_ms = ONE launch between synchronisations (HIP events; agrees with the rocprofv3 per-dispatch average under "
-                                      "profiles/r03); kernel_ms_train = per-launch interval of back-to-back launches of the same kernel (consecutive "
+                                      "profiles/r04); kernel_ms_train = per-launch interval of back-to-back launches of the same kernel (consecutive "
                                       "launches overlap head to tail, so it is shorter and is what `value` is made of); step_interval_ms = the same for the "
                                       "whole step (one launch while no instance has active vertical inequality rows; a batch beyond the resident size that "
                                       "does defer instances takes two: the tick kernel, then one wavefront per deferred instance).  No MFMA on this "
                                       "path: bound = FP64 vector issue."),
         }
+        if grp is not None:
+            from quadruped_gait_generation_ismpc_amd import group as G
+            res["multi_gpu"] = {"rccl_world": grp.world, "rccl_version": G.rccl_version(), "path": "abi", "kernel_ms": kernel_ms_train,
+                                "exposed_collective_ms": collective_ms, "overlapped_step_ms": 1e3 * wall / K}
         if pipe is not None:
-            res["multi_gpu"] = {"kernel_ms": kernel_ms_train, "collective_ms": collective_ms, "overlapped_step_ms": 1e3 * wall / K}
+            res["multi_gpu"] = {"rccl_world": (R.dist.get_world_size() if not R.rehearse else None), "path": "torch", "kernel_ms": kernel_ms_train,
+                                "collective_ms": collective_ms, "overlapped_step_ms": 1e3 * wall / K}
         if extras and world == 1:
             # PCIe-inclusive rate through the host-pointer entry point (H2D of the inputs and D2H of the outputs
             # inside the metric) -- never `value`.  Page-locked caller buffers: zero copy (the kernel reads and writes them in place
@@ -606,6 +681,61 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
         res["sweep"] = dict(info, mfma_flops=flops, build_tflops=flops / (info["build_ms"] * 1e-3) / 1e12 if info["build_ms"] > 0 else None,
                             note="tables of every set built on the device: Newton-Schulz inverse of the vertical Hessians as batched v_mfma_f64_16x16x4_f64 products "
                                  "(csrc/ismpc_sweep.hip); build_ms = the whole build (all kernels), build_tflops = the MFMA products' flops over it")
+    if grp is not None:
+        grp.close()
+    solver.close()
+    return res
+
+
+def leg_group_one(R, q, N, batch, K, W, min_ms):
+    """At --gpus 1: the multi-GPU entry points of the C ABI on the one GPU there is -- a group of one device (ncclCommInitAll), the
+    double-buffered ismpc_group_step_device with its in-place ncclAllGather on the side stream.  Reports what RCCL itself says about the
+    communicator (ncclCommCount) and the step time of the pipelined path; NOT a scaling measurement."""
+    torch = R.torch
+    from quadruped_gait_generation_ismpc_amd import group as G, workload
+    p = q.default_params(N=N)
+    g = G.Group(q.reference_plan(params=p), p, devices=[R.local_rank])
+    d_in = q.to_device(workload.make_batch(N, batch), R.dev)
+    g.reserve(batch); torch.cuda.synchronize()
+    walls = timed_regions(R, lambda k: g.step_device(batch, [d_in.data_ptr()], k & 1), K, W, min_ms, drain=g.sync)
+    wall = statistics.median(walls)
+    res = {"rccl_world": g.world, "rccl_version": G.rccl_version(), "path": "abi", "mode": "one process, ncclCommInitAll over 1 device (no scaling curve measured)",
+           "group_step_ms": 1e3 * wall / K, "group_value": batch / (wall / K)}
+    g.close()
+    return res
+
+
+def leg_sustained(R, q, N, batch, seconds, ticks=2000):
+    """SURVEY 8 row f1 as a throughput figure, and the one leg long enough for an outside utilisation sampler to see: the closed loop
+    on the device (ismpc_rollout_device: Controller.cpp:297-310,346-348,503-504 around solve(), the tick loop inside one launch),
+    `ticks` ticks x `batch` instances per call from the same perturbed start, calls back to back for at least `seconds` of GPU time."""
+    torch = R.torch
+    p = q.default_params(N=N)
+    rows = 8 + (ticks + 2 * N) // (p.S + p.F) + 1                      # the plan covers first_frame + ticks + 2 N samples
+    solver = q.MPCSolver(q.reference_plan(rows=rows, params=p), params=p, device=R.local_rank)
+    st0 = np.repeat(np.zeros(1, dtype=q.TICK_IN), batch); st0["com_pos"][:, 2] = p.h_des
+    rng = np.random.default_rng(1)
+    st0["com_pos"][:, :2] += rng.uniform(-0.004, 0.004, (batch, 2)); st0["com_vel"][:, :2] += rng.uniform(-0.02, 0.02, (batch, 2))
+    d0 = q.to_device(st0, R.dev); d = d0.clone()
+    solver.rollout_torch(d, 0, 20, want_traj=False); torch.cuda.synchronize()
+    calls, t0 = 0, time.perf_counter()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    while True:
+        for _ in range(8):
+            d.copy_(d0); solver.rollout_torch(d, 0, ticks, want_traj=False); calls += 1
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 >= seconds:
+            break
+    b.record(); torch.cuda.synchronize()
+    gpu_s = a.elapsed_time(b) * 1e-3
+    fin = q.from_device(d, q.TICK_IN)
+    # one tick of the final state through the per-tick entry point: its status word says whether the loop stayed inside the plan
+    st = q.from_device(solver.solve_batch_torch(d), q.TICK_OUT)["status"]
+    res = {"name": "closed loop on the device (ismpc_rollout_device), N=%d, %d instances x %d ticks per call" % (N, batch, ticks),
+           "value": batch * ticks * calls / gpu_s, "unit": "ticks/s", "gpu_seconds": gpu_s, "calls": calls, "ticks_per_call": ticks, "batch": batch,
+           "us_per_tick": 1e6 * gpu_s / (calls * ticks), "final_control_iter_max": int(fin["control_iter"].max()),
+           "final_status_bad_index": int(((st & q.ST_BAD_INDEX) != 0).sum()), "final_status_error": int(((st & q.ST_ERROR_MASK) != 0).sum())}
     solver.close()
     return res
 
@@ -662,9 +792,27 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
         per_inst = False
     dpush = torch.from_numpy(push.copy()).to(R.dev)
     d = d0.clone()
-    all_out = torch.empty((world * batch, 80), dtype=torch.uint8, device=("cpu" if R.rehearse else R.dev)) if R.collective else None
+    ga = None
+    if R.collective and R.abi and not R.rehearse:
+        # the native group (include/ismpc_group.h): this rank's `batch` instances are shard `rank` of a global batch of world x batch
+        from quadruped_gait_generation_ismpc_amd import group as G
+        if name == "mc_C200":
+            ga = G.GroupA.from_rank(FA.default_params(0, C=Cn, P=Pn, F=Fn), plans[0], R.local_rank, R.unique_id(), rank, world); ga.add_plan(plans[1])
+        else:
+            ga = G.GroupA.from_rank(FA.default_params(w["kind"], C=Cn, P=Pn, F=Fn), ce, R.local_rank, R.unique_id(), rank, world)
+        ga.set_precision(dtype == "f32")
+        assert ga.world == world and ga.shard(world * batch) == (rank * batch, batch)
+        ga.reserve(world * batch)
+    all_out = torch.empty((world * batch, 80), dtype=torch.uint8, device=("cpu" if R.rehearse else R.dev)) if (R.collective and ga is None) else None
     last = [None]
     evs = []
+    ts = torch.cuda.current_stream(R.dev).cuda_stream
+
+    def group_step(k):
+        d.copy_(d0)                                                      # (torch's stream) the caller's replay of the pushed state ...
+        ga.order_after(0, ts)                                            # ... which the group's launch stream waits for
+        ga.step_device(world * batch, [d.data_ptr()], [d_inst.data_ptr()] if name == "mc_C200" else None, [dpush.data_ptr()], k & 1)
+        ga.wait_on(0, k & 1, ts)                                         # the next copy into `d` comes after this step's kernel (and collective)
 
     def step(k):
         d.copy_(d0)
@@ -674,11 +822,18 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
         if all_out is not None:
             gather_records(o.cpu() if R.rehearse else o, world, out=all_out, counts=[batch] * world, force=True)
 
-    walls = timed_regions(R, step, K, W, min_ms)
+    if ga is not None:
+        walls = timed_regions(R, group_step, K, W, min_ms, drain=ga.sync)
+        gathered = q.from_device(ga.result_torch(world * batch, 0, (K - 1) & 1).clone(), FA.OUT_A)
+        timed_regions(R, step, 3, 1, 0.0)                                # the same tick through the plain handle: kernel_ms and the bytes to compare with
+    else:
+        walls = timed_regions(R, step, K, W, min_ms)
     wall = statistics.median(walls)
     torch.cuda.synchronize()
-    kernel_ms = statistics.median(a.elapsed_time(b) for a, b in evs[W:])
+    kernel_ms = statistics.median(a.elapsed_time(b) for a, b in evs[(1 if ga is not None else W):])
     o = q.from_device(last[0], FA.OUT_A)
+    if ga is not None:
+        assert gathered[rank * batch:(rank + 1) * batch].tobytes() == o.tobytes(), "group all-gather misplaced or altered this rank's shard"
     res = None
     if rank == 0:
         act = ((o["active"] & 0xffff) + (o["active"] >> 16)) / 2.0
@@ -700,14 +855,129 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
             "roofline": roofline(legkey, kname, kernel_ms, batch, dtype, flops, 136.0 * batch,
                                  note="kernel_ms = HIP events around every tick call of the timed regions, median (the state copy precedes the first event; "
                                       "prologue launch, the wave kernel and, behind an fp32 launch, the fp64 re-solve launch inside; the wave kernel is 97-99 % "
-                                      "of it: compare the rocprofv3 average under profiles/r03).  algorithmic_credit = SURVEY 8d flops_A = 2[nv w^2 + w^3/3 + "
+                                      "of it: compare the rocprofv3 average under profiles/r04).  algorithmic_credit = SURVEY 8d flops_A = 2[nv w^2 + w^3/3 + "
                                       "4 nv w + 6 nv], nv = C+F, w = measured mean working-set size (a dense active-set solve; the structured solver executes "
                                       "less).  fp32 legs execute fp64 instructions too (right-hand sides, prefix sums, the LIP update): both types are counted."),
         }
         if dtype == "f32":
             res["config"]["deferred_to_fp64"] = int(gen.last_deferred())
+        if ga is not None:
+            res["multi_gpu"] = {"rccl_world": ga.world, "path": "abi", "kernel_ms": kernel_ms, "overlapped_step_ms": 1e3 * wall / K}
+    if ga is not None:
+        ga.close()
     gen.close()
     return res
+
+
+# ======================================================================================================================
+# The ONE line: numbers only, <= LINE_LIMIT bytes; everything else goes to bench_detail.json
+# ======================================================================================================================
+def _sig(x, n=5):
+    """n significant digits (the line is size-limited; bench_detail.json keeps full precision)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float(f"{float(x):.{n}g}")
+    except (TypeError, ValueError):
+        return x
+
+
+def compact_roofline(rf, full=True):
+    if not rf:
+        return None
+    ex = rf.get("executed") or {}
+    out = {"frac": _sig(rf.get("frac"), 4), "kernel": rf.get("kernel"), "kernel_ms": _sig(rf.get("kernel_ms")), "traffic": _sig(rf.get("traffic"))}
+    if full:
+        out = {"bound": rf.get("bound"), "achieved": _sig(rf.get("achieved")), "peak": _sig(rf.get("peak")), "unit": rf.get("unit"),
+               "frac": _sig(rf.get("frac"), 4), "traffic": _sig(rf.get("traffic")), "kernel": rf.get("kernel"), "kernel_ms": _sig(rf.get("kernel_ms")),
+               "kernel_ms_train": _sig(rf.get("kernel_ms_train")), "algorithmic_credit": {"tflops": _sig((rf.get("algorithmic_credit") or {}).get("tflops")),
+                                                                                         "bytes_per_launch": _sig((rf.get("algorithmic_credit") or {}).get("bytes_per_launch"))},
+               "valu_busy_frac": _sig(ex.get("valu_busy_frac"), 3), "fp_share": _sig(ex.get("fp_share_of_valu_instructions"), 3),
+               "pmc_matches_lib": (rf.get("pmc_lib_sha256") is not None and rf.get("pmc_lib_sha256") == rf.get("lib_sha256"))}
+    return out
+
+
+def compact_cpu(cb, full=True):
+    if not cb:
+        return None
+    out = {"value": _sig(cb.get("value"), 4)}
+    if full:
+        s = str(cb.get("sample", ""))
+        out = {"value": _sig(cb.get("value"), 4), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+               "sample": s if len(s) <= 200 else s[:197] + "...",
+               "all_cores": {"value": _sig((cb.get("all_cores") or {}).get("value"), 4), "cores": (cb.get("all_cores") or {}).get("cores")},
+               "own": ({"value": _sig(cb["own"]["value"], 4), "kind": "port", "cores": 1} if cb.get("own") else None),
+               "cpu_model": cb.get("cpu_model"), "nproc": cb.get("nproc")}
+    return out
+
+
+def compact_line(full, detail_path):
+    """The driver's line from the full result: the contract's keys, numeric roofline and cpu_baseline, other_configs cut to numbers."""
+    cfg = full.get("config", {})
+    wl = str(cfg.get("workload", ""))
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value"] = _sig(full.get("value"), 7); line["ms_per_step"] = _sig(full.get("ms_per_step"), 6)
+    line["qp_solves_per_s"] = _sig(full.get("qp_solves_per_s"), 7)
+    line["config"] = {"workload": wl if len(wl) <= 220 else wl[:217] + "...", "horizon": cfg.get("horizon"), "global_batch": cfg.get("global_batch"),
+                      "batch_per_gpu": cfg.get("batch_per_gpu"), "active_box_fraction": _sig(cfg.get("active_box_fraction"), 3)}
+    line["regions"] = full.get("regions"); line["region_ms_median"] = _sig((full.get("region_ms") or {}).get("median"))
+    line["roofline"] = compact_roofline(full.get("roofline"))
+    if full.get("cpu_baseline"):
+        line["cpu_baseline"] = compact_cpu(full["cpu_baseline"])
+    for k in ("value_incl_pcie", "value_incl_pcie_pageable", "latency_batch1_us"):
+        if k in full:
+            line[k] = _sig(full[k], 4)
+    if full.get("multi_gpu"):
+        line["multi_gpu"] = {k: _sig(v) for k, v in full["multi_gpu"].items() if not isinstance(v, (dict, list)) and not (isinstance(v, str) and len(v) > 48)}
+    if full.get("sustained"):
+        su = full["sustained"]
+        line["sustained"] = {"leg": "ismpc_rollout_device closed loop", "value": _sig(su["value"], 6), "unit": su["unit"], "gpu_seconds": _sig(su["gpu_seconds"], 4),
+                             "batch": su["batch"], "ticks_per_call": su["ticks_per_call"], "calls": su["calls"]}
+    oc = []
+    for o in full.get("other_configs", []):
+        c = {"name": (o["name"] if len(o["name"]) <= 96 else o["name"][:93] + "..."), "value": _sig(o.get("value"), 6), "ms_per_step": _sig(o.get("ms_per_step")),
+             "dtype": o.get("dtype"), "roofline": compact_roofline(o.get("roofline"), full=False)}
+        if o.get("cpu_baseline"):
+            c["cpu_baseline"] = compact_cpu(o["cpu_baseline"], full=False)
+        oc.append(c)
+    if oc:
+        line["other_configs"] = oc
+    line["detail"] = detail_path
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:               # never over the limit: shed the optional parts, most dispensable first
+        for k in ("other_configs", "sustained", "multi_gpu"):
+            if k == "other_configs" and "other_configs" in line:
+                line["other_configs"] = [{"name": c["name"][:60], "value": c["value"], "ms_per_step": c["ms_per_step"], "dtype": c["dtype"],
+                                          "roofline": {"frac": (c.get("roofline") or {}).get("frac")}} for c in line["other_configs"]]
+            elif k in line:
+                del line[k]
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+    while len(text) > LINE_LIMIT and line.get("other_configs"):
+        line["other_configs"].pop(); line["other_configs_dropped"] = line.get("other_configs_dropped", 0) + 1      # (they are all in the detail file)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
+def write_detail(full):
+    """bench_detail.json next to bench.py (and a copy under gpurun_out/ when that directory exists: it is what travels back from a GPU box)."""
+    path = os.path.join(ROOT, DETAIL_NAME)
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        go = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(go):
+            with open(os.path.join(go, DETAIL_NAME), "w") as f:
+                json.dump(full, f, indent=1)
+    except OSError as e:
+        print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    return DETAIL_NAME
+
+
+def emit(full):
+    print(compact_line(full, write_detail(full)), flush=True)
 
 
 # ======================================================================================================================
@@ -730,7 +1000,12 @@ def main():
     ap.add_argument("--only", default=None, help="run ONE leg and print it as the line: headline | config1_b1024 | config3_walk_C150 | "
                                                   "config4_mc_C200 | shard_b8192 | shard_b16384 | shard_b32768 | sweep_k64_b65536 | a_walk_C100 | a_trot_C160 (profiling runs: one kernel shape per process)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="with --only <Formulation A leg>: arithmetic type of the QP solve")
+    ap.add_argument("--sustained-seconds", type=float, default=8.0, help="GPU seconds of the sustained closed-loop leg (0: skip it)")
+    ap.add_argument("--full-line", action="store_true", help="print the full result object (what bench_detail.json holds) instead of the compact line "
+                                                              "(profiling scripts that keep one leg's complete object)")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes from this process even for --gpus 1 (the launcher path of `--gpus N` as typed)")
+    ap.add_argument("--collective", default="abi", choices=["abi", "torch"], help="who issues the all-gather at N > 1: the native library's own RCCL communicator "
+                                                                                   "(include/ismpc_group.h; default) or torch.distributed's nccl backend (A/B)")
     ap.add_argument("--force-collective", action="store_true", help="build the RCCL group and run the path's all-gather even with ONE rank "
                                                                      "(exercises communicator set-up and the side-stream pipeline on a one-GPU box; moves no bytes between GPUs)")
     ap.add_argument("--launcher-selftest", type=int, default=None, help=argparse.SUPPRESS)   # rank that fails (-1: none); no GPU is touched
@@ -750,7 +1025,7 @@ def main():
         time.sleep(0.5 if args.launcher_selftest < 0 else 30)
         return
 
-    R = Ranks(args.gpus, force_collective=args.force_collective)
+    R = Ranks(args.gpus, force_collective=args.force_collective, collective=args.collective)
     world, rank = R.world, R.rank
     import quadruped_gait_generation_ismpc_amd as q
     K, W, M = args.steps, args.warmup, args.min_region_ms
@@ -798,12 +1073,20 @@ def main():
             if args.only in a_legs:
                 line["steps"] = a_steps; line["warmup"] = 2
             with_cpu(line, args.only if args.only in a_legs else "B")
-            print(json.dumps(line), flush=True)
+            if args.full_line:
+                print(json.dumps(line), flush=True)
+            else:
+                emit(line)
         R.close()
         return
 
     head = LEGS["headline"]()
     others = []
+    sustained = None
+    if world == 1 and "multi_gpu" not in head:
+        head["multi_gpu"] = leg_group_one(R, q, args.horizon, args.global_batch, K, W, M)
+    if world == 1 and args.sustained_seconds > 0:
+        sustained = leg_sustained(R, q, args.horizon, args.global_batch, args.sustained_seconds)
     if not args.no_other_configs:
         if world == 1:
             r1 = LEGS["config1_b1024"]()
@@ -845,7 +1128,12 @@ def main():
                     r4f["cpu_baseline"] = r4["cpu_baseline"]
                 others.append(r4f)
             line["other_configs"] = others
-        print(json.dumps(line), flush=True)
+        if sustained is not None:
+            line["sustained"] = sustained
+        if args.full_line:
+            print(json.dumps(line), flush=True)
+        else:
+            emit(line)
     R.close()
 
 

@@ -206,6 +206,10 @@ int         ismpc_midpoint_rows(const ismpc_handle* h);   /* rows*(S+F), MPCSolv
 int         ismpc_get_midpoint(const ismpc_handle* h, double* dst, int capacity_rows);
 /* Last kernel time of ismpc_solve_batch* in milliseconds measured with HIP
  * events on the launch stream (0 when timing is disabled).                 */
+/* The handle's four self-resetting counters of the inequality fallback, after draining the device: entries in the
+ * deferred list, fallback workgroups done, instances parked by an in-kernel rollout, resume workgroups done.  All four
+ * are 0 between calls, whatever was launched before (ticks, rollouts, hipGraph replays of a captured step).          */
+int         ismpc_fallback_counters(ismpc_handle* h, int* out4);
 int         ismpc_set_timing(ismpc_handle* h, int enabled);
 double      ismpc_last_kernel_ms(ismpc_handle* h);
 

@@ -32,7 +32,7 @@ EXPORTS = ["ismpc_params_default", "ismpc_create", "ismpc_destroy", "ismpc_solve
            "ismpc_solve_batch_device", "ismpc_rollout_device", "ismpc_abi_version", "ismpc_last_error",
            "ismpc_get_params", "ismpc_midpoint_rows", "ismpc_get_midpoint", "ismpc_set_timing",
            "ismpc_last_kernel_ms", "ismpc_reserve", "ismpc_host_alloc", "ismpc_host_free", "ismpc_host_register",
-           "ismpc_host_unregister", "ismpc_create_sweep", "ismpc_sweep_info", "ismpc_sweep_verify_tables"]
+           "ismpc_host_unregister", "ismpc_create_sweep", "ismpc_sweep_info", "ismpc_sweep_verify_tables", "ismpc_fallback_counters"]
 
 _lib = None
 
@@ -80,6 +80,7 @@ def load():
     lib.ismpc_create_sweep.argtypes = [vp, ci, vp, ci, ci, C.POINTER(vp)]; lib.ismpc_create_sweep.restype = ci
     lib.ismpc_sweep_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(cd)]; lib.ismpc_sweep_info.restype = ci
     lib.ismpc_sweep_verify_tables.argtypes = [vp, ci, vp]; lib.ismpc_sweep_verify_tables.restype = ci
+    lib.ismpc_fallback_counters.argtypes = [vp, vp]; lib.ismpc_fallback_counters.restype = ci
     _lib = lib
     return lib
 
@@ -89,21 +90,23 @@ def last_error():
 
 
 class PinnedRecords:
-    """A numpy array of records in page-locked host memory (ismpc_host_alloc): what the pipelined host entry point
-    ismpc_solve_batch wants on both sides.  `.array` is the view; the memory is freed when this object is."""
+    """A numpy array of records in page-locked host memory (ismpc_host_alloc): what the zero-copy host entry point
+    ismpc_solve_batch wants on both sides.  `.array` is the view.  The block is released when the LAST numpy view of it dies
+    (the finalizer is keyed to the buffer object every view's `.base` chain ends in), so a slice or a reshape that outlives this
+    object, or a call to free(), never points at freed memory."""
 
     def __init__(self, n, dtype):
         import weakref
         lib = load()
-        self._p = C.c_void_p()
+        p = C.c_void_p()
         nbytes = max(int(n), 1) * np.dtype(dtype).itemsize
-        rc = lib.ismpc_host_alloc(nbytes, C.byref(self._p))
+        rc = lib.ismpc_host_alloc(nbytes, C.byref(p))
         if rc != 0:
             raise MemoryError(f"ismpc_host_alloc({nbytes}): {rc}: {last_error()}")
-        buf = (C.c_uint8 * nbytes).from_address(self._p.value)
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        weakref.finalize(buf, lib.ismpc_host_free, C.c_void_p(p.value))
         self.array = np.frombuffer(buf, dtype=dtype, count=int(n))
-        self._fin = weakref.finalize(self, lib.ismpc_host_free, C.c_void_p(self._p.value))
 
     def free(self):
+        """Drops this object's view; the memory goes when no other view of it is left."""
         self.array = None
-        self._fin()

@@ -1,6 +1,6 @@
 """Builds the in-tree native libraries with hipcc for gfx950 (no JIT cache, no torch extension):
 
-  libismpc_hip.so   kernels + C ABI of include/ismpc.h, include/ismpc_a.h   (csrc/*.hip, csrc/ismpc_tables.cpp)
+  libismpc_hip.so   kernels + C ABI of include/ismpc.h, include/ismpc_a.h, include/ismpc_group.h   (csrc/*.hip, csrc/ismpc_tables.cpp)
 
 The C++ MPCSolver drop-in (include/MPCSolver.hpp) is header-only over that ABI.
 """
@@ -44,10 +44,10 @@ def build(force=False, verbose=False, out=None, flags=None):
     flags = os.environ.get("ISMPC_HIPCC_FLAGS", "") if flags is None else flags
     if out is None and flags.strip():
         raise RuntimeError("non-default compiler flags need an explicit output path: build(out=..., flags=...) and ISMPC_LIB=<out>")
-    units = ["ismpc_hip.hip", "ismpc_sweep.hip", "ismpc_a_hip.hip", "ismpc_a_wave_rl2.hip", "ismpc_a_wave_rl3.hip", "ismpc_a_wave_rl4.hip", "ismpc_tables.cpp"]
+    units = ["ismpc_hip.hip", "ismpc_sweep.hip", "ismpc_a_hip.hip", "ismpc_a_wave_rl2.hip", "ismpc_a_wave_rl3.hip", "ismpc_a_wave_rl4.hip", "ismpc_group.hip", "ismpc_tables.cpp"]
     hip_src = [os.path.join(CSRC, u) for u in units]
     deps = hip_src + [os.path.join(CSRC, h) for h in ("ismpc_tables.hpp", "ismpc_sweep.hpp", "ismpc_a_dev.hpp", "ismpc_a_wave.hpp")] + \
-        [os.path.join(ROOT, "include", "ismpc.h"), os.path.join(ROOT, "include", "ismpc_a.h")]
+        [os.path.join(ROOT, "include", "ismpc.h"), os.path.join(ROOT, "include", "ismpc_a.h"), os.path.join(ROOT, "include", "ismpc_group.h")]
     quiet = None if verbose else subprocess.DEVNULL
     if force or _stale(target, deps, flags):
         objdir = os.path.join(ROOT, "build", "obj", os.path.basename(target))
@@ -65,7 +65,7 @@ def build(force=False, verbose=False, out=None, flags=None):
             if pr.wait() != 0:
                 raise subprocess.CalledProcessError(pr.returncode, f"hipcc -c {src}")
             objs.append(obj)
-        subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", target], stdout=quiet)
+        subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-ldl", "-o", target], stdout=quiet)
         with open(target + ".flags", "w") as f:
             f.write(flags)
     return target

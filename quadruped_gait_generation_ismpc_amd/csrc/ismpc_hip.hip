@@ -58,8 +58,13 @@ struct DevConst {
     const double *HSt, *SHSt;
     const DevConst* sets; int nsets;  // parameter sweeps (ismpc_create_sweep): one record per parameter set, its own tables and scalars; the
                                       // instance's record names its set (ismpc_tick_in.reserved).  NULL / 0 for a plain handle
-    int* zflag;                       // id of the last launch that deferred an instance to the fallback kernel
-    int* zseen;                       // the same id in a word of host memory (written, never read, by the device): how the host picks the launch form
+    int* zflag;                       // four self-resetting counters (zeroed once, at ismpc_create): [0] entries in the deferred list of the
+                                      // running two-launch step, [1] fallback workgroups done with it, [2] instances an in-kernel rollout
+                                      // parked for its resume launch, [3] resume workgroups done.  The consumer launch exits at once on a
+                                      // zero count; otherwise its LAST workgroup zeroes the pair again -- so the counters are valid whatever
+                                      // launched before (a rollout between two ticks, hipGraph replays of one captured step: the count does
+                                      // not depend on launch ids and no memset sits outside a captured step)
+    int* zseen;                       // id of the last launch that deferred an instance, in a word of host memory (written, never read, by the device): how the host picks the launch form
     double* zpool; int* zbusy;        // active-set fallback: slots of zstride doubles (G^-1 cap x cap + per-entry vectors), one lock word per slot
     int zslots, zcap, zldsq; size_t zstride;   // zldsq: entries the fallback keeps in its LDS window before it moves to a slot (Z_LDS_Q; ISMPC_Z_LDS_Q lowers it: tests)
     // sample-major copies for ismpc_tick_quad: a lane's R samples are one contiguous run (16-byte loads, one base address)
@@ -172,12 +177,11 @@ __device__ __forceinline__ void sinhc_coshc(double w, double& P, double& Q)
 }
 
 // Caller bookkeeping in front of solve(): Controller.cpp:297-304 (enabled) and :310.
-// Per-launch scratch of the inequality fallback, one allocation: batch mark bytes (padded to 16), then the LIST of deferred
-// instances (batch ints) and two counters.  The per-tick kernel of launch `lid` appends to the list under counter lid & 1; the
-// fallback launch behind it walks exactly those entries (scanning 65 536 marks with 256 wavefronts cost 0.5 ms whenever
-// anything was deferred) and clears the OTHER counter for the next launch.
-__host__ __device__ inline size_t zscratch_bytes(int batch) { return (((size_t)batch + 15) & ~(size_t)15) + 4 * (size_t)batch + 16; }
-__device__ __forceinline__ int* zlist_of(unsigned char* zmark, int batch) { return reinterpret_cast<int*>(zmark + (((size_t)batch + 15) & ~(size_t)15)); }
+// Per-launch scratch of the inequality fallback of the two-launch form: the LIST of deferred instances (batch ints).  The per-tick
+// kernel appends an instance under the handle's counter DevConst::zflag[0]; the fallback launch behind it walks exactly those entries
+// (scanning 65 536 marks with 256 wavefronts cost 0.5 ms whenever anything was deferred) and its last workgroup zeroes the counter.
+__host__ __device__ inline size_t zscratch_bytes(int batch) { return 4 * (size_t)batch + 16; }
+__device__ __forceinline__ int* zlist_of(unsigned char* zmark, int) { return reinterpret_cast<int*>(zmark); }
 struct Walk { double sim; int mpc, ctl, fc; };
 __device__ __forceinline__ Walk load_walk(const DevConst& c, const ismpc_tick_in* rec, int rollout_frame)
 {
@@ -1094,10 +1098,9 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
     }
     // ---- closed loop: feed back (Controller.cpp:346-348) and advance counters (:503-504)
     if constexpr (!FB) {
-        if (zmark && lane == 0) zmark[gi] = deferred ? 1 : 0;
-        if (deferred && lane == 0) {
-            atomicMax(c.zflag, launch_id);
-            if (zlist) zlist[atomicAdd(zlist + zbatch + (launch_id & 1), 1)] = gi;
+        if (deferred && lane == 0 && zlist) {
+            const int slot = atomicAdd(c.zflag, 1);
+            if (slot < zbatch) zlist[slot] = gi;            // (an instance appends once per step and the count starts at 0: always true)
         }
     }
     if (rollout_frame >= 0 && lane == 0 && !deferred && !(status & ISMPC_ST_Z_FAILED)) {   // a failed vertical solve is flagged, never fed back
@@ -1658,8 +1661,10 @@ __device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_
     const bool deferred = tick_group_core<R, LPI, KF, SW>(c, lane, s, o, (u_traj && valid) ? u_traj + (size_t)gi * 3 * c.N : nullptr, lds_wave);
     if ((lane & (LPI - 1)) == 0 && valid) {
         if (out) store_record(out + gi, o);
-        if (zmark) zmark[gi] = deferred ? 1 : 0;
-        if (deferred) { atomicMax(c.zflag, launch_id); if (c.zseen) *c.zseen = launch_id; if (zlist) zlist[atomicAdd(zlist + batch + (launch_id & 1), 1)] = gi; }
+        if (deferred) {
+            if (c.zseen) *c.zseen = launch_id;
+            if (zlist) { const int slot = atomicAdd(c.zflag, 1); if (slot < batch) zlist[slot] = gi; }
+        }
         if (rollout_frame >= 0 && !deferred) store_feedback(c, state_rw + gi, o, s.w);
     }
     STAMP(5);                                         // stores issued
@@ -1780,7 +1785,7 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
     const int lane = threadIdx.x & 63, li = lane & (LPI - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
-    if constexpr (FB) { if (*c.zflag != launch_id) return; }
+    if constexpr (FB) { if (*(volatile int*)(c.zflag + 2) == 0) return; }      // nothing parked (workgroup-uniform: the first launch is done)
     const int nwork = FB ? batch : (batch + IPW - 1) / IPW;          // FB: one instance per wavefront (every group computes it, group 0 stores)
     for (int work = wave; work < nwork; work += FB ? (int)gridDim.x * ISMPC_QUAD_WAVES : nwork) {
         const int gi_raw = FB ? work : work * IPW + lane / LPI;
@@ -1842,9 +1847,13 @@ void ismpc_rollout_quad(const DevConst c, ismpc_tick_in* state, ismpc_tick_out* 
             }
             if constexpr (!FB) {
                 stop_tick[gi] = stopped;
-                if (stopped >= 0) atomicMax(c.zflag, launch_id);
+                if (stopped >= 0) atomicAdd(c.zflag + 2, 1);
             }
         }
+    }
+    if constexpr (FB) {      // the last resume workgroup zeroes the parked count for the next rollout (see DevConst::zflag)
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(c.zflag + 3, 1) == (int)gridDim.x - 1) { c.zflag[2] = 0; c.zflag[3] = 0; __threadfence(); }
     }
 }
 
@@ -1855,15 +1864,14 @@ void ismpc_tick_affine_fallback(const DevConst c, const ismpc_tick_in* __restric
                                 ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
                                 unsigned char* zmark, int launch_id)
 {
-    int* zl = zlist_of(zmark, batch);
-    if (blockIdx.x == 0 && threadIdx.x == 0) zl[batch + ((launch_id + 1) & 1)] = 0;       // the next launch's counter (its previous user, launch_id - 1, is done)
-    if (*c.zflag != launch_id) return;
+    const int* zl = zlist_of(zmark, batch);
+    const int ndef = min(*(volatile int*)c.zflag, batch);     // stable while this launch runs (the appending kernel is done): workgroup-uniform
+    if (ndef == 0) return;
     __shared__ double zlds[4][Z_LDS_DOUBLES];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave0 = blockIdx.x * 4 + wv;
     double* const zwin = zlds[wv];
-    const int ndef = min(zl[batch + (launch_id & 1)], batch);
     for (int k = wave0; k < ndef; k += gridDim.x * 4) {
         const int gi = __builtin_amdgcn_readfirstlane(zl[k]);
         {
@@ -1874,6 +1882,9 @@ void ismpc_tick_affine_fallback(const DevConst c, const ismpc_tick_in* __restric
             } else tick_affine_body<R, true>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, nullptr, 0, zwin);
         }
     }
+    // every workgroup has read the count by the time it gets here; the last one to arrive hands the counters back zeroed
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(c.zflag + 1, 1) == (int)gridDim.x - 1) { c.zflag[0] = 0; c.zflag[1] = 0; __threadfence(); }
 }
 
 // ------------------------------------------------------------------------
@@ -1912,7 +1923,6 @@ struct ismpc_handle {
     int one_launch = 2;       // 2: one launch per step (ismpc_tick_quad_inline up to the resident size; beyond it ismpc_tick_quad_one unless recent launches deferred instances); 1: only the former; 0: never; 3: always
     int force_waves = 0;      // dense path: 4, 8 or 16 wavefronts per workgroup (0 = 16)
     unsigned char* zmark = nullptr; int zmark_cap = 0; int launch_id = 0; bool z_fallback = true;
-    int zlist_batch = -1;        // batch whose deferred-list counters (inside the zmark allocation, at batch-dependent offsets) are initialised
     int* zstop = nullptr; int zstop_cap = 0;     // in-kernel rollouts: tick at which an instance was handed to the resume launch (-1: never)
     bool dense_path = false;  // true: per-tick MFMA solve (ismpc_tick_dense); false: affine tables (ismpc_tick_affine)
     int cus = 0;              // compute units of the device (kernel variant selection); 0: never the one-launch variant
@@ -1985,11 +1995,18 @@ hipError_t grow_sync(ismpc_handle* h, hipStream_t s)
     if (h->used && h->last_stream != s) return hipStreamSynchronize(h->last_stream);
     return hipSuccess;
 }
-bool host_is_pinned(const void* p)
+// Page-locked AND device-mapped over its whole length: both ends of [p, p + bytes) are host allocations known to the runtime and the
+// device addresses of the two ends are `bytes - 1` apart (one mapping, or adjacent ones that continue each other).  A registration that
+// covers only the head of the buffer, or an interior pointer near the end of a pinned block, fails this and takes the staged path
+// instead of letting the kernel touch unmapped host memory over PCIe.
+bool host_is_pinned(const void* p, size_t bytes)
 {
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
+    if (!p || bytes == 0) return false;
+    hipPointerAttribute_t a, b;
+    const char* last = static_cast<const char*>(p) + (bytes - 1);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess || hipPointerGetAttributes(&b, last) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a.type != hipMemoryTypeHost || b.type != hipMemoryTypeHost) return false;
+    return a.devicePointer && b.devicePointer && static_cast<const char*>(b.devicePointer) - static_cast<const char*>(a.devicePointer) == (ptrdiff_t)(bytes - 1);
 }
 struct StreamMark { ismpc_handle* h; hipStream_t s; ~StreamMark() { h->last_stream = s; h->used = true; } };
 
@@ -2009,11 +2026,7 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
             if (h->zmark) HIP_TRY(hipFreeAsync(h->zmark, s));
             h->zmark = nullptr; h->zmark_cap = 0;
             HIP_TRY(hipMallocAsync((void**)&h->zmark, zscratch_bytes(batch), s));
-            h->zmark_cap = batch; h->zlist_batch = -1;
-        }
-        if (h->z_fallback && h->zlist_batch != batch) {   // the two counters of the deferred list sit behind `batch` marks and `batch` entries
-            HIP_TRY(hipMemsetAsync(h->zmark + zscratch_bytes(batch) - 16, 0, 16, s));
-            h->zlist_batch = batch;
+            h->zmark_cap = batch;
         }
         unsigned char* zm = h->z_fallback ? h->zmark : nullptr;
         const int lid = ++h->launch_id;
@@ -2211,7 +2224,7 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
     if (rc == ISMPC_OK) rc = upload(h, t.SW, &c.SW);
     if (rc == ISMPC_OK) rc = upload(h, t.HSt, &c.HSt);
     if (rc == ISMPC_OK) rc = upload(h, t.SHSt, &c.SHSt);
-    if (rc == ISMPC_OK) { std::vector<int> zf(1, 0); const int* zp = nullptr; rc = upload(h, zf, &zp); c.zflag = const_cast<int*>(zp); }
+    if (rc == ISMPC_OK) { std::vector<int> zf(4, 0); const int* zp = nullptr; rc = upload(h, zf, &zp); c.zflag = const_cast<int*>(zp); }
     if (rc == ISMPC_OK) {
         // one word of page-locked host memory the kernels write the launch id to when they defer an instance (see launch())
         void* hp = nullptr; void* dp = nullptr;
@@ -2447,7 +2460,7 @@ int ismpc_solve_batch(ismpc_handle* h, int batch, const ismpc_tick_in* in_host, 
     // zero copy needs device-visible addresses for the caller's records (page-locked AND mapped: hipHostMalloc / hipHostRegister give
     // both under unified addressing); anything else -- also a registration without a device mapping -- takes the staged path
     const ismpc_tick_in* zc_in = nullptr; ismpc_tick_out* zc_out = nullptr;
-    bool zero_copy = h->host_mode != 0 && !h->dense_path && host_is_pinned(in_host) && host_is_pinned(out_host);
+    bool zero_copy = h->host_mode != 0 && !h->dense_path && host_is_pinned(in_host, sizeof(ismpc_tick_in) * (size_t)batch) && host_is_pinned(out_host, sizeof(ismpc_tick_out) * (size_t)batch);
     if (zero_copy && (hipHostGetDevicePointer((void**)&zc_in, const_cast<ismpc_tick_in*>(in_host), 0) != hipSuccess ||
                       hipHostGetDevicePointer((void**)&zc_out, out_host, 0) != hipSuccess)) { (void)hipGetLastError(); zero_copy = false; }
     if (batch > h->st_cap && !(zero_copy && h->host_mode == 3)) {      // device staging (not needed when both sides are in place)
@@ -2573,7 +2586,7 @@ int ismpc_reserve(ismpc_handle* h, int max_batch)
         if (h->zmark) HIP_TRY(hipFree(h->zmark));
         h->zmark = nullptr; h->zmark_cap = 0;
         HIP_TRY(hipMalloc((void**)&h->zmark, zscratch_bytes(max_batch)));
-        h->zmark_cap = max_batch; h->zlist_batch = -1;
+        h->zmark_cap = max_batch;
     }
     if (max_batch > h->zstop_cap) {
         if (h->zstop) HIP_TRY(hipFree(h->zstop));
@@ -2592,6 +2605,15 @@ int ismpc_debug_stamps(unsigned long long* dst, int reset)
     return 0;
 }
 #endif
+
+int ismpc_fallback_counters(ismpc_handle* h, int* out4)
+{
+    if (!h || !out4) return fail(ISMPC_E_INVALID, "null argument");
+    ON_DEVICE(h);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out4, h->c.zflag, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    return ISMPC_OK;
+}
 
 int ismpc_get_params(const ismpc_handle* h, ismpc_params* out)
 {

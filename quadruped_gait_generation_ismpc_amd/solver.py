@@ -99,6 +99,10 @@ class MPCSolver:
         self.params_list = list(params_list)
         self.params = self.params_list[0]
         self.ftsp = np.ascontiguousarray(ftsp_and_timings, dtype=np.float64)
+        if self.ftsp.ndim != 2 or self.ftsp.shape[1] != 4:
+            raise ValueError("ftsp_and_timings must be rows x 4")
+        if not self.params_list:
+            raise ValueError("a sweep needs at least one parameter set")
         arr = (Params * len(self.params_list))(*self.params_list)
         h = C.c_void_p()
         rc = self._lib.ismpc_create_sweep(C.cast(arr, C.c_void_p), len(self.params_list), self.ftsp.ctypes.data_as(C.c_void_p),
@@ -175,6 +179,16 @@ class MPCSolver:
         self._check(self._lib.ismpc_rollout_device(self._h, int(batch), C.c_void_p(state_ptr), int(first_frame), int(ticks),
                                                    C.c_void_p(traj_ptr) if traj_ptr else None,
                                                    C.c_void_p(stream) if stream else None))
+
+    def reserve(self, max_batch):
+        """Sizes the handle's per-launch scratch now (ismpc_reserve): callers that capture launches into a hipGraph call this first."""
+        self._check(self._lib.ismpc_reserve(self._h, int(max_batch)))
+
+    def fallback_counters(self):
+        """ismpc_fallback_counters: (deferred-list entries, fallback workgroups done, parked instances, resume workgroups done); all 0 between calls."""
+        a = np.zeros(4, dtype=np.int32)
+        self._check(self._lib.ismpc_fallback_counters(self._h, a.ctypes.data_as(C.c_void_p)))
+        return tuple(int(v) for v in a)
 
     def set_timing(self, enabled=True):
         self._check(self._lib.ismpc_set_timing(self._h, 1 if enabled else 0))

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Regenerates the measurement tables of DESIGN.md section 5 from the files committed under profiles/r03/ (bench lines printed by
-scripts/profile_r03.sh, rocprofv3 kernel stats, PMC summaries, kernel_resources.md) -- the numbers in the document cannot go stale.
+"""Regenerates the measurement tables of DESIGN.md section 5 from the files committed under profiles/r04/ (bench lines printed by
+scripts/profile_r04.sh, rocprofv3 kernel stats, PMC summaries, kernel_resources.md) -- the numbers in the document cannot go stale.
 usage: python scripts/design_tables.py            (rewrites the block between the GENERATED markers of DESIGN.md)"""
 import csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "profiles", "r03")
+P = os.path.join(ROOT, "profiles", "r04")
 
 
 def line(path):
@@ -106,7 +106,7 @@ if os.path.exists(vp):
 block = "\n".join(out) + "\n\n" + "\n\n".join(extra) + "\n"
 path = os.path.join(ROOT, "DESIGN.md")
 txt = open(path).read()
-b, e = "<!-- BEGIN GENERATED:r03 (scripts/design_tables.py) -->", "<!-- END GENERATED:r03 -->"
+b, e = "<!-- BEGIN GENERATED:r04 (scripts/design_tables.py) -->", "<!-- END GENERATED:r04 -->"
 if b in txt and e in txt:
     txt = txt[:txt.index(b) + len(b)] + "\n" + block + txt[txt.index(e):]
     open(path, "w").write(txt)

@@ -17,6 +17,22 @@ for f in sorted(glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv"
             sums[c] = sums.get(c, 0.0) + float(row["Counter_Value"]); cnts[c] = cnts.get(c, 0) + 1
 mean = {c: sums[c] / cnts[c] for c in sorted(sums)}
 res = {"kernel": kern, "launches_averaged": max(cnts.values()) if cnts else 0, "counters_mean_per_launch": mean}
+# what ties this summary to a binary: the sha256 of the library the profiled process loaded (bench.py::roofline refuses a summary whose
+# hash is not the loaded library's) and the commit the tree was at (GRAFT_GIT_HEAD / git rev-parse; "unknown" on a box without .git)
+import hashlib, subprocess
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = os.environ.get("ISMPC_LIB") or os.path.join(_root, "quadruped_gait_generation_ismpc_amd", "libismpc_hip.so")
+try:
+    res["lib_sha256"] = hashlib.sha256(open(_lib, "rb").read()).hexdigest()
+except OSError:
+    res["lib_sha256"] = None
+head = os.environ.get("ISMPC_GIT_HEAD")
+if not head:
+    try:
+        head = subprocess.run(["git", "-C", _root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        head = None
+res["git_head"] = head or "unknown"
 for k, v in extra.items():
     try: res[k] = json.loads(v)
     except Exception: res[k] = v

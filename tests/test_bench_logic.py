@@ -15,16 +15,21 @@ def bench(tmp_path, monkeypatch):
     spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
     monkeypatch.setenv("ISMPC_PROFILES_DIR", str(tmp_path))
+    monkeypatch.setattr(b, "lib_sha256", lambda path=None: SHA)          # the library "loaded" in these tests
     return b, tmp_path
 
 
-def _pmc(path, leg, batch, kernel, fl64, fl32, valu, active=None, busy=None, fetch=1000.0, write=500.0):
+SHA = "5" * 64
+
+
+def _pmc(path, leg, batch, kernel, fl64, fl32, valu, active=None, busy=None, fetch=1000.0, write=500.0, sha=SHA):
     c = {"SQ_INSTS_VALU": valu}
     if active is not None:
         c["SQ_ACTIVE_INST_VALU"] = active; c["SQ_BUSY_CYCLES"] = busy
     d = {"flops_f64_per_launch": fl64, "flops_f32_per_launch": fl32, "fp_insts_f64_per_launch": fl64 / 100.0, "fp_insts_f32_per_launch": fl32 / 100.0,
          "fp_share_of_valu_insts": 0.4, "hbm_bytes_per_launch": 2.0 * fetch * 1024 + write * 1024}
-    json.dump({"kernel": kernel, "batch": batch, "leg": leg, "launches_per_step": 1, "counters_mean_per_launch": c, "derived": d}, open(path / f"pmc_{leg}.json", "w"))
+    json.dump({"kernel": kernel, "batch": batch, "leg": leg, "launches_per_step": 1, "counters_mean_per_launch": c, "derived": d, "lib_sha256": sha, "git_head": "abc1234"},
+              open(path / f"pmc_{leg}.json", "w"))
 
 
 def test_roofline_is_executed_work_over_the_blended_peak(bench):
@@ -80,3 +85,65 @@ def test_kernel_names_and_credits_follow_the_launch_rules(bench, monkeypatch):
     assert b.flops_a(150, 4, 0.0) == 2 * 6 * 154
     assert b.a_kernel_name(150, 4, False, "f32") == "ismpc_a_tick_wave<float, 3, 4, false>"
     assert b.a_kernel_name(200, 6, True, "f64") == "ismpc_a_tick_wave<double, 4, 6, true>"
+
+
+def test_a_counter_summary_of_another_build_is_not_used(bench):
+    """pmc_*.json carries the sha256 of the library it was collected from (scripts/pmc_summary.py); bench.py derives achieved / frac /
+    traffic from it only when that is the library loaded now."""
+    b, tmp = bench
+    _pmc(tmp, "headline_b65536", 65536, "ismpc_tick_quad<", 8e8, 0.0, 2.2e7, sha="0" * 64)
+    rf = b.roofline("headline_b65536", "ismpc_tick_quad<13, 8, false>", 0.05, 65536, "f64", 4e9, 1e7)
+    assert rf["achieved"] is None and rf["frac"] is None and rf["traffic"] is None and rf["executed"] is None and "STALE" in rf["note"]
+    assert rf["algorithmic_credit"]["tflops"] > 0 and rf["pmc_lib_sha256"] == "0" * 64 and rf["lib_sha256"] == SHA
+    assert b.compact_roofline(rf)["pmc_matches_lib"] is False and b.compact_roofline(rf)["frac"] is None
+    _pmc(tmp, "headline_b65536", 65536, "ismpc_tick_quad<", 8e8, 0.0, 2.2e7)              # same counters, collected from the loaded library
+    rf = b.roofline("headline_b65536", "ismpc_tick_quad<13, 8, false>", 0.05, 65536, "f64", 4e9, 1e7)
+    assert rf["frac"] == pytest.approx(8e8 / 0.05e-3 / 1e12 / 78.6) and b.compact_roofline(rf)["pmc_matches_lib"] is True
+    # the real hash function: a file's sha256, cached per path, None for a missing library
+    import hashlib, importlib.util
+    spec = importlib.util.spec_from_file_location("bench_real", os.path.join(ROOT, "bench.py"))
+    real = importlib.util.module_from_spec(spec); spec.loader.exec_module(real)
+    f = tmp / "lib.so"; f.write_bytes(b"\x7fELF" + bytes(1000))
+    assert real.lib_sha256(str(f)) == hashlib.sha256(f.read_bytes()).hexdigest() and real.lib_sha256(str(tmp / "missing.so")) is None
+
+
+def test_the_line_stays_under_the_limit_and_keeps_the_contract(bench, tmp_path):
+    """Round 3's line was 27 KB and the driver (8 KB tail) could not parse it.  The line now carries numbers only; the full objects go to
+    bench_detail.json.  Built here from a synthetic full result with every leg and prose notes of round-3 length."""
+    b, tmp = bench
+    note = "x" * 1500
+    def leg(name, dtype="f64"):
+        rf = {"bound": "valu", "achieved": 15.2, "peak": 78.6, "unit": "TFLOP/s", "frac": 0.1934567, "traffic": 1.24e7, "kernel": "ismpc_a_tick_wave<double, 4, 6, true>",
+              "kernel_ms": 0.0515, "kernel_ms_train": 0.0479, "algorithmic_credit": {"flops_per_launch": 4.06e9, "tflops": 78.9, "bytes_per_launch": 9.96e6, "note": note},
+              "executed": {"valu_busy_frac": 0.7, "fp_share_of_valu_instructions": 0.45, "valu_issue_note": note}, "peak_note": note, "note": note,
+              "lib_sha256": SHA, "pmc_lib_sha256": SHA}
+        cb = {"value": 815.3, "unit": "ticks/s", "cores": 1, "kind": "reference", "sample": "s" * 400, "all_cores": {"value": 1.06e4, "cores": 16, "note": note},
+              "own": {"value": 300.0, "cores": 1, "kind": "port", "sample": note}, "cpu_model": "AMD EPYC 9575F 64-Core Processor", "nproc": 256}
+        return {"name": name + " " + "n" * 150, "value": 1.31e9, "unit": "ticks/s (1 tick = ...)", "ms_per_step": 0.0499, "dtype": dtype, "qp_solves_per_s": 3.9e9,
+                "regions": 23, "region_ms": {"median": 2.2, "min": 2.1, "max": 2.4}, "config": {"workload": "w" * 600, "horizon": 100, "global_batch": 65536,
+                "batch_per_gpu": 65536, "active_box_fraction": 0.19}, "roofline": rf, "cpu_baseline": cb, "incl_pcie_note": note}
+    full = leg("headline")
+    full.update({"metric": "ISMPC QP solves/s (batch, N=100 horizon)", "n_gpus": 1, "steps": 20, "warmup": 5, "higher_is_better": True, "scaling": "strong",
+                 "vs_baseline": None, "data": "synthetic", "value_incl_pcie": 3.1e8, "value_incl_pcie_pageable": 2.4e8, "latency_batch1_us": 17.2,
+                 "multi_gpu": {"rccl_world": 1, "group_step_ms": 0.06, "note": note},
+                 "sustained": {"value": 1.7e9, "unit": "ticks/s", "gpu_seconds": 8.2, "batch": 65536, "ticks_per_call": 2000, "calls": 105},
+                 "other_configs": [leg("BASELINE configs[%d]" % k, "f32" if k % 2 else "f64") for k in range(8)]})
+    text = b.compact_line(full, "bench_detail.json")
+    assert len(text) <= 6000 and "\n" not in text
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "other_configs", "sustained", "multi_gpu", "detail"):
+        assert k in d, k
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["global_batch"] == 65536
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "kernel_ms_train", "algorithmic_credit", "pmc_matches_lib"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["frac"] == pytest.approx(0.1935, abs=1e-4) and d["roofline"]["algorithmic_credit"]["tflops"] == pytest.approx(78.9)
+    for k in ("value", "unit", "cores", "kind", "sample", "all_cores", "own"):
+        assert k in d["cpu_baseline"], k
+    assert len(d["other_configs"]) == 8 and all(set(o) >= {"name", "value", "ms_per_step", "dtype", "roofline", "cpu_baseline"} for o in d["other_configs"])
+    assert "x" * 40 not in text and '"note"' not in text                                           # no prose notes in the line
+    assert d["multi_gpu"]["rccl_world"] == 1
+    # a pathological number of legs still fits: the optional parts are shed, the contract keys stay
+    full["other_configs"] = [leg("leg %d" % k) for k in range(40)]
+    text = b.compact_line(full, "bench_detail.json")
+    assert len(text) <= 6000 and json.loads(text)["roofline"]["frac"] is not None

@@ -476,6 +476,52 @@ def test_one_launch_and_two_launch_forms_agree_bitwise(q, sweep, monkeypatch):
     assert torch.equal(ta, tb) and torch.equal(sa, sb)
 
 
+def test_deferred_list_counter_survives_rollouts_and_graph_replays(q, monkeypatch):
+    """The deferred list of the two-launch form is counted by a self-resetting counter of the handle (DevConst::zflag): the fallback's last
+    workgroup zeroes it.  Round 3 keyed two counters to the parity of the launch id, which a rollout between two ticks (it consumes an id
+    without touching the list) or a hipGraph replay of one captured step (same id every time) turned into a count that only grew -- the
+    fallback then re-solved instances nobody deferred and the append index ran past the list.  Here: tick, in-kernel rollout, tick on ONE
+    handle against fresh handles, then one captured two-launch step replayed eight times; bytes equal and all counters back at zero."""
+    import torch
+    from quadruped_gait_generation_ismpc_amd import workload
+    B = 40000                                                    # beyond the resident size: the list is in use
+    p = q.default_params(N=100, z_ineq_hi=4.6)
+    plan = q.reference_plan(params=p)
+    monkeypatch.setenv("ISMPC_ONE_LAUNCH", "0")                   # the two-launch form on every step
+    tin = workload.make_batch(100, B, seed=77)
+    frame = int(tin["simulation_time"].max()) + 1
+    h = q.MPCSolver(plan, params=p)
+    d_in = q.to_device(tin)
+    o1 = h.solve_batch_torch(d_in).clone()
+    st = d_in.clone(); h.rollout_torch(st, frame, 3, want_traj=False)          # consumes a launch id, parks and resumes instances
+    o2 = h.solve_batch_torch(d_in).clone()
+    o3 = h.solve_batch_torch(st).clone()
+    torch.cuda.synchronize()
+    assert h.fallback_counters() == (0, 0, 0, 0)
+    f1, f2 = q.MPCSolver(plan, params=p), q.MPCSolver(plan, params=p)
+    r1 = f1.solve_batch_torch(d_in); st2 = d_in.clone(); f2.rollout_torch(st2, frame, 3, want_traj=False); r3 = f2.solve_batch_torch(st2)
+    torch.cuda.synchronize()
+    act = (q.from_device(r1, q.TICK_OUT)["status"] & q.ST_Z_INEQ_ACTIVE) != 0
+    assert act.sum() > 100
+    assert torch.equal(o1, r1) and torch.equal(o2, r1) and torch.equal(st, st2) and torch.equal(o3, r3)
+    # one captured step, replayed: the scratch is sized first (no allocation inside the capture), the handle warmed up before the capture
+    g = q.MPCSolver(plan, params=p); g.reserve(B)
+    out = torch.empty((B, 80), dtype=torch.uint8, device="cuda:0")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g.solve_batch_torch(d_in, out); side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            g.solve_batch_torch(d_in, out)
+    for k in range(8):
+        out.zero_(); graph.replay(); torch.cuda.synchronize()
+        assert torch.equal(out, r1), k
+        c = g.fallback_counters()
+        assert c == (0, 0, 0, 0), (k, c)
+    for s_ in (h, f1, f2, g):
+        s_.close()
+
+
 @pytest.mark.parametrize("lay,host", [("affine", "hostloop"), ("lpi8", "hostloop8"), ("lpi32", "hostloop32")])
 @pytest.mark.parametrize("N,ticks,over", [(100, 300, dict()), (50, 200, dict()), (100, 200, dict(z_ineq_hi=5.0)), (50, 200, dict(z_ineq_hi=1.3))])
 def test_in_kernel_rollout_is_bitwise_the_per_tick_loop(q, O, N, ticks, over, lay, host):
