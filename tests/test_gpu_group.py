@@ -60,7 +60,7 @@ def test_python_group_pipeline_and_formulation_a(built_libs):
             assert got.tobytes() == np.roll(ref, -(k - 1)).tobytes(), k
     g.sync(); g.close()
     gr = G.Group.from_rank(plan, p, 0, G.unique_id(), 0, 1)
-    assert gr.world == 1 and gr.solve_batch(tin[:777]).tobytes() == ref[:777].tobytes()
+    assert gr.world == 1 and gr.solve_batch(tin[:777]).tobytes() == plain.solve_batch(tin[:777]).tobytes()      # (777 instances: another lane layout than 12 000)
     gr.close(); plain.close()
     # Formulation A, per-instance gait parameters, fp32 solve
     BA = 4096
