@@ -33,6 +33,7 @@
 #pragma once
 #include <cmath>
 #include <algorithm>
+#include <type_traits>
 #include "ismpc_a_dev.hpp"
 
 namespace ismpc_a {
@@ -207,6 +208,11 @@ __device__ __forceinline__ double with_flag(double v, bool f) { return __longlon
 __device__ __forceinline__ bool flag_of(float v) { return (__float_as_int(v) & 1) != 0; }
 __device__ __forceinline__ bool flag_of(double v) { return (__double_as_longlong(v) & 1ll) != 0; }
 
+#ifndef ISMPC_A_GCAP
+#define ISMPC_A_GCAP 8
+#endif
+constexpr int GCAP = ISMPC_A_GCAP;     // Gram sums of a block solve accumulated per pass (a power of two; 64 = all at once, as rounds 1-3 did)
+
 // ---- per-wavefront LDS.  Small vectors (length m = 2F+1 or F+2) are kept ONE ELEMENT PER LANE in registers and mirrored here
 // when other lanes need them by index; nothing of size "working set" is stored anywhere.
 template <typename R, int F> struct WaveLds {
@@ -224,14 +230,17 @@ template <typename R, int F> struct WaveLds {
 };
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// value held by the owner of ZMP row `row` (1-based, wave-uniform) in a per-row register array
+// value held by the owner of ZMP row `row` (1-based, wave-uniform) in a per-row register array.  Every element is read from the owner
+// lane and the wave-uniform position picks among the SCALARS: written as a select among the lane's own registers followed by one
+// readlane, the compiler turned the (uniform) index into an index into a private array -- three scratch stores and a dependent scratch
+// load per call, which was all of the scratch traffic of the shapes that spill nothing (7-15x the algorithmic HBM bytes, round 3).
 template <typename V, int RL> __device__ __forceinline__ V at_row(const V (&v)[RL], int row)
 {
     const int o = (row - 1) / RL, k = (row - 1) - o * RL;
-    V x = v[0];
+    V x = rl(v[0], o);
 #pragma unroll
-    for (int r = 1; r < RL; ++r) if (k == r) x = v[r];
-    return rl(x, o);
+    for (int r = 1; r < RL; ++r) { const V y = rl(v[r], o); x = (k == r) ? y : x; }
+    return x;
 }
 // b^n, 0 <= n < 2048, by repeated squaring (per-instance gait parameters: every weight of the stability row and of the
 // anticipative tail is a power of lambda = exp(-eta dt); one exp per QP instead of seven, a pow, a cosh and a sinh)
@@ -451,21 +460,31 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             const double lamC = ipow(lam, C);
             const double k1c = (1 / eta) * (1 - lam) / (1 - lamC), k2c = c.dt * 1.0 * lamC;
             double* padw = pad_pi[PI ? wv : 0]; double* pa2dw = pa2d_pi[PI ? wv : 0];
-            double av[RL], cum[RL], cum2[RL], loc = 0.0, sqs = 0.0;
-            // a_i = k1c lambda^i - k2c: one exp per lane (its first row), then powers of lambda
-            double lp = ipow(lam, lane * RL);
+            // a_i = k1c lambda^i - k2c: one power per lane (its first row), then powers of lambda.  Two sweeps over the lane's rows --
+            // totals for the scan first, the running sums second -- so that no per-row fp64 array lives across the scans
+            double loc = 0.0, sqs = 0.0;
+            const double lp0 = ipow(lam, lane * RL);
+            {
+                double lp = lp0;
 #pragma unroll
-            for (int k = 0; k < RL; ++k) {
-                const int i0 = lane * RL + k;
-                av[k] = (i0 < C) ? k1c * lp - k2c : 0.0;
-                lp *= lam;
-                loc += av[k]; cum[k] = loc; sqs += av[k] * av[k]; cum2[k] = sqs;
+                for (int k = 0; k < RL; ++k) {
+                    const double avk = (lane * RL + k < C) ? k1c * lp - k2c : 0.0;
+                    lp *= lam;
+                    loc += avk; sqs += avk * avk;
+                }
             }
-            const double base = wave_scan_up(loc) - loc, base2 = wave_scan_up(sqs) - sqs;
+            double run = wave_scan_up(loc) - loc, run2 = wave_scan_up(sqs) - sqs;
+            {
+                double lp = lp0;
+                asm volatile("" : "+v"(lp));                              // (opaque: the second sweep is not folded back into per-row arrays of the first)
 #pragma unroll
-            for (int k = 0; k < RL; ++k) {
-                const int i0 = lane * RL + k;
-                if (i0 < C) { aw[i0] = (R)av[k]; paw[i0 + 1] = (R)(base + cum[k]); padw[i0 + 1] = base + cum[k]; pa2dw[i0 + 1] = base2 + cum2[k]; }
+                for (int k = 0; k < RL; ++k) {
+                    const int i0 = lane * RL + k;
+                    const double avk = (i0 < C) ? k1c * lp - k2c : 0.0;
+                    lp *= lam;
+                    run += avk; run2 += avk * avk;
+                    if (i0 < C) { aw[i0] = (R)avk; paw[i0 + 1] = (R)run; padw[i0 + 1] = run; pa2dw[i0 + 1] = run2; }
+                }
             }
             if (lane == 0) { paw[0] = R(0); padw[0] = 0.0; pa2dw[0] = 0.0; }
             aa = (R)wave_sum(sqs);
@@ -610,36 +629,42 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             // ---- small quasi-definite system  [[I+G11, G1x],[Gx1, Gxx - Sxx]] cc = rhs (L.hx), G in L.G; unknown order:
             // 0..F-1 footstep columns, F = stability row, F+1..2F = Khat_1..F (rows outside kmask: pinned to 0).  Returns
             // this lane's cc[lane] and leaves cc in L.cc.
-            auto solve_small = [&](const unsigned long long kmask) __attribute__((always_inline)) -> R {
+            // NOK (a compile-time tag): no kinematic row is in the working set -- always true in the block passes, usually in the exact
+            // steps.  The pinned unknowns F+1..2F then decouple (their rows and columns are unit vectors, their right-hand sides 0): the
+            // elimination runs on the leading (F+1) x (F+1) block only -- (F+1)(F+2)/2 row updates instead of (F+1)(3F+2)/2, and no loads
+            // of the pinned columns -- and gives the same numbers (the dropped updates multiply exact zeros).
+            auto solve_small = [&](auto NOK, const unsigned long long kmask) __attribute__((always_inline)) -> R {
                 LANE_FRESH();
+                constexpr bool nok = decltype(NOK)::value;
+                constexpr int mu_ = nok ? F + 1 : m;                                // unknowns the elimination touches
                 // lane i < m owns row i of the augmented matrix in registers; the pivot row travels by readlane: no LDS
                 // traffic and no barriers inside the elimination
                 const int i = lane < m ? lane : m - 1;
-                const bool ipin = i > F && !((kmask >> (i - F)) & 1ull);
-                R Tr[m + 1];
+                const bool ipin = i > F && (nok || !((kmask >> (i - F)) & 1ull));
+                R Tr[mu_ + 1];
 #pragma unroll
-                for (int jj = 0; jj < m; ++jj) {
+                for (int jj = 0; jj < mu_; ++jj) {
                     R val = L.G[i * m + jj];                                        // G plus the constant part (identity, -Sxx): see gkind
                     if (jj == F && i == F) val = -Dee;                              // G_EE - a'a without the cancellation
-                    const bool jpin = jj > F && !((kmask >> (jj - F)) & 1ull);
+                    const bool jpin = !nok && jj > F && !((kmask >> (jj - F)) & 1ull);
                     if (ipin || jpin) val = (i == jj) ? R(-1) : R(0);
                     Tr[jj] = val;
                 }
-                Tr[m] = ipin ? R(0) : L.hx[i];
+                Tr[mu_] = ipin ? R(0) : L.hx[i];
 #pragma unroll
-                for (int kk = 0; kk < m; ++kk) {                                 // Gauss-Jordan, no pivoting (quasi-definite)
-                    if (kk > F && !((kmask >> (kk - F)) & 1ull)) continue;       // pinned unknown: its column is already e_kk
+                for (int kk = 0; kk < mu_; ++kk) {                               // Gauss-Jordan, no pivoting (quasi-definite)
+                    if (!nok && kk > F && !((kmask >> (kk - F)) & 1ull)) continue;   // pinned unknown: its column is already e_kk
                     if (PI && kk < F && kk >= Fi) continue;                      // footstep beyond this instance's horizon: no row maps to
                                                                                  // it, its row and column of G are zero, the pivot is 1
                     const R ipv = frcp(rl(Tr[kk], kk));
                     const R fct = (lane == kk) ? R(0) : Tr[kk] * ipv;
 #pragma unroll
-                    for (int jj = kk + 1; jj <= m; ++jj) Tr[jj] -= fct * rl(Tr[jj], kk);
+                    for (int jj = kk + 1; jj <= mu_; ++jj) Tr[jj] -= fct * rl(Tr[jj], kk);
                 }
-                R dg = Tr[0];
+                R dg = nok ? R(-1) : Tr[0];                                      // (a pinned row of the reduced form: diagonal -1, right-hand side 0)
 #pragma unroll
-                for (int jj = 1; jj < m; ++jj) if (lane == jj) dg = Tr[jj];
-                const R cc_e = (lane < m) ? Tr[m] * frcp(dg) : R(0);             // lane e: cc[e]
+                for (int jj = (nok ? 0 : 1); jj < mu_; ++jj) if (lane == jj) dg = Tr[jj];
+                const R cc_e = (lane < m) ? Tr[mu_] * frcp(dg) : R(0);           // lane e: cc[e]
                 if (lane < m) L.cc[lane] = cc_e;
                 WAVE_LDS_SYNC();
                 PH(3);                                     // 3: small system (Gauss-Jordan)
@@ -707,29 +732,53 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                         }
                     };
                     {
+                        // The NS = (F+2)(F+3)/2 - 1 sums are taken in passes of at most GCAP accumulators (round 4): all of them at once is 20
+                        // live registers at F = 4 and 35 at F = 6 on top of a lane's rows, which is what the three- and four-rows-per-lane shapes
+                        // spilled to scratch (<double,3,4,false> 14 registers, <float,4,6,true> 32: 7-106x the algorithmic HBM traffic).  A pass
+                        // re-forms the pair differences of the lane's rows (a few loads from LDS) and keeps only its own products; the
+                        // decomposition into power-of-two chunks that the fold works on is the one wave_fold_sums has always used up to F = 5
+                        // (bit-identical sums), at F = 6 the leading chunk of 32 becomes two of 16.
                         constexpr int NS = NT + NR;
-                        R acc[NS];
+                        auto gram = [&](auto self, auto S_) __attribute__((always_inline)) -> void {
+                            constexpr int S = decltype(S_)::value;
+                            if constexpr (S < NS) {
+                                constexpr int E = (NS - S >= GCAP) ? S + GCAP : NS, NP = E - S;
+                                R acc[NP];
 #pragma unroll
-                        for (int t = 0; t < NS; ++t) acc[t] = R(0);
+                                for (int t = 0; t < NP; ++t) acc[t] = R(0);
 #pragma unroll
-                        for (int k = 0; k < RL; ++k) {
-                            const int i = lane * RL + k + 1;
-                            if (i <= C && STA_(k) != 0) {
-                                R dth[F], om, dE, dc;
-                                pair_diffs(k, dth, om, dE, dc);
-                                int t = 0;
+                                for (int k = 0; k < RL; ++k) {
+                                    const int i = lane * RL + k + 1;
+                                    if (i <= C && STA_(k) != 0) {
+                                        R dth[F], om, dE, dc;
+                                        pair_diffs(k, dth, om, dE, dc);
+                                        int t = 0;
 #pragma unroll
-                                for (int r = 0; r < F; ++r) {
-                                    const R od = om * dth[r];
+                                        for (int r = 0; r < F; ++r) {
+                                            const R od = om * dth[r];
 #pragma unroll
-                                    for (int q = r; q < F; ++q) acc[t++] += od * dth[q];
-                                    acc[NT + r] += od * dE; acc[NT + F + r] += od * dc;
+#define G_IN(t_) ((t_) >= S && (t_) < E)
+#define G_AT(t_) acc[G_IN(t_) ? (t_) - S : 0]           /* (the index of a sum that is not this pass's is never used: no out-of-range constant) */
+                                            for (int q = r; q < F; ++q) { if (G_IN(t)) G_AT(t) += od * dth[q]; ++t; }
+                                            if (G_IN(NT + r)) G_AT(NT + r) += od * dE;
+                                            if (G_IN(NT + F + r)) G_AT(NT + F + r) += od * dc;
+                                        }
+                                        if (G_IN(NT + 2 * F)) G_AT(NT + 2 * F) += om * dE * dE;
+                                        if (G_IN(NT + 2 * F + 1)) G_AT(NT + 2 * F + 1) += om * dE * dc;
+#undef G_IN
+#undef G_AT
+                                    }
                                 }
-                                acc[NT + 2 * F] += om * dE * dE; acc[NT + 2 * F + 1] += om * dE * dc;
+                                if constexpr (NP == GCAP) {
+                                    const R part = fold_pow2<R, GCAP, 1>(acc, lane);
+                                    const R tot = finish_sum<R, GCAP>(part);
+                                    if (lane < GCAP) L.th[S + lane] = tot;
+                                } else wave_fold_sums<R, NP>(acc, L.th + S, lane);
+                                self(self, std::integral_constant<int, E>{});
                             }
-                        }
-                        PH(5);                             // 5: block solve: Gram accumulation
-                        wave_fold_sums<R, NS>(acc, L.th, lane);
+                        };
+                        gram(gram, std::integral_constant<int, 0>{});
+                        PH(5);                             // 5: block solve: Gram accumulation (and, since round 4, the folds)
                     }
                     WAVE_LDS_SYNC();
                     PH(6);                                 // 6: block solve: fold over the wavefront
@@ -760,7 +809,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 PH(7);                                     // 7: block solve: G and right-hand side from the sums
                 Dd = stability_defect(); Dee = (R)Dd;
                 PH(8);                                     // 8: block solve: stability defect
-                (void)solve_small(kmask);
+                if (kmask == 0ull) (void)solve_small(std::true_type{}, 0ull); else (void)solve_small(std::false_type{}, kmask);
                 const R cEw = L.cc[F];
                 // comb[r] = (cc[r-1] - ck[r] + ck[r+1]) / sqrt(Qf), r = 1..F: what a row sees through its two footstep columns
                 // (ck = the kinematic unknowns, 0 where pinned)
@@ -1144,7 +1193,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                     const unsigned long long kmask = __builtin_amdgcn_ballot_w64(klane && kact != 0);   // bit r: Khat_r active
                     Dee = (R)Dd;
                     PH(12);                                // 12: Goldfarb-Idnani: one step (new row, neighbours, right-hand side ...)
-                    const R cc_e = solve_small(kmask);
+                    const R cc_e = (kmask == 0ull) ? solve_small(std::true_type{}, 0ull) : solve_small(std::false_type{}, kmask);
                     const R cE = L.cc[F];
                     // ---- y = coefficients on the V columns (delta_Z - V cc = sg dt^2 k_i + V y); rows see the footstep
                     // columns through comb[k1], comb[k1+1]:  comb[r] = (yM_r - yK_r + yK_{r+1}) / sqrt(Qf)
@@ -1401,15 +1450,29 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #endif
         const bool ok = (status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) == 0;
         const double u0 = ok ? (double)rl(u[0], 0) : 0.0;
-        const double f0 = ok ? cur + (double)rl(fr, 1) : cur;
+        const double df0 = ok ? (double)rl(fr, 1) : 0.0;                          // first footstep, relative to the current one
         if (lane == 0) {
-            const double p0 = pos, v0 = vel, z0 = zmp;
+            // The instance's record is READ AGAIN here, by this one lane, instead of staying live -- in scalar registers, it is wave-uniform --
+            // across the whole solve: position, velocity, ZMP, current footstep, counters and (per-instance) the gait parameters were a
+            // quarter of the scalar registers the solver phases had to spill around (round 4).  state_in is the launch's read-only copy.
+            const ismpc_a_state* sp = state_in + inst;
+            asm volatile("" : "+v"(sp));                                         // a per-lane address: a vector load of lane 0, not a scalar one
+            const double p0 = axis == 0 ? sp->x : sp->y, z0 = axis == 0 ? sp->xz : sp->yz, cur2 = axis == 0 ? sp->cur_x : sp->cur_y;
+            double v0 = axis == 0 ? sp->xd : sp->yd;
+            if (push) { const double* pp = push + inst * 2 + axis; asm volatile("" : "+v"(pp)); v0 += *pp; }
+            const int j2 = sp->j, fc2 = sp->fc;
+            int step2 = c.step; double eta2 = c.eta;
+            if (PI) {
+                const ismpc_a_inst* ipp = ipar + inst; asm volatile("" : "+v"(ipp));
+                if (!(status & ISMPC_A_ST_BAD_INDEX)) { step2 = ipp->step; eta2 = sqrt(c.grav / ipp->height); }
+            }
+            const double f0 = cur2 + df0;
             double np_, nv_, nz_;
             if (PI) {                                                            // A_upd, B_upd for this instance's eta (:67-71)
                 const double e_ = lam_pi, ie_ = 1.0 / e_;
                 const double ch = 0.5 * (ie_ + e_), sh = 0.5 * (ie_ - e_);          // cosh, sinh of eta dt
-                np_ = (ch * p0 + (sh / eta) * v0 + (1 - ch) * z0) + (c.dt - sh / eta) * u0;
-                nv_ = ((eta * sh) * p0 + ch * v0 + (-eta * sh) * z0) + (1 - ch) * u0;
+                np_ = (ch * p0 + (sh / eta2) * v0 + (1 - ch) * z0) + (c.dt - sh / eta2) * u0;
+                nv_ = ((eta2 * sh) * p0 + ch * v0 + (-eta2 * sh) * z0) + (1 - ch) * u0;
                 nz_ = (0.0 * p0 + 0.0 * v0 + 1.0 * z0) + c.dt * u0;
             } else {
                 np_ = (c.Au[0] * p0 + c.Au[1] * v0 + c.Au[2] * z0) + c.Bu[0] * u0;
@@ -1417,19 +1480,19 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 nz_ = (c.Au[6] * p0 + c.Au[7] * v0 + c.Au[8] * z0) + c.Bu[2] * u0;
             }
             ismpc_a_state* so = state + inst;
-            const bool stepped = ok && (j + 1 >= step_ * fc);
+            const bool stepped = ok && (j2 + 1 >= step2 * fc2);
             if (ok) {
                 if (axis == 0) { so->x = np_; so->xd = nv_; so->xz = nz_; } else { so->y = np_; so->yd = nv_; so->yz = nz_; }
                 if (stepped) {
-                    const double noff = f0 - fs[fc];
+                    const double noff = f0 - fs[fc2];
                     if (axis == 0) { so->cur_x = f0; so->off_x = noff; } else { so->cur_y = f0; so->off_y = noff; }
                 }
-                if (axis == 0) { so->j = j + 1; if (stepped) { so->fc = fc + 1; so->rebuilt = 1; } }
+                if (axis == 0) { so->j = j2 + 1; if (stepped) { so->fc = fc2 + 1; so->rebuilt = 1; } }
             }
             if (out) {
                 ismpc_a_out* o = out + inst;
                 const int q = 1 + qz + qk;
-                o->com_before[axis] = pos; o->vel_after[axis] = ok ? nv_ : vel; o->u0[axis] = u0; o->f0[axis] = f0;
+                o->com_before[axis] = p0; o->vel_after[axis] = ok ? nv_ : v0; o->u0[axis] = u0; o->f0[axis] = f0;
                 if (axis == 0) { o->iters_x = iters; atomicOr(&o->status, status); atomicOr(&o->active, q & 0xffff); }
                 else { o->iters_y = iters; atomicOr(&o->status, status); atomicOr(&o->active, (q & 0xffff) << 16); }
             }

@@ -516,8 +516,11 @@ def test_full_batch_properties_and_oracle_sample(FA, workload_name, precision, s
     B = 16384
     backend = "ref" if O.have_ref() else "gi"
     f32 = precision == "f32"
-    tol_u0 = 2e-3 if f32 else TOL_U0[backend]
-    tol_f0, tol_v = (2e-5, 5e-6) if f32 else (1e-7, 1e-6)
+    # fp32 solve: 2x the maxima measured on these very samples (gpurun_out/parity_maxima.jsonl, round 4: 128 / 64 oracle instances per case,
+    # eleven cases: u0 <= 2.2e-5 relative -- the size of qpOASES's own distance from the exact minimiser, TOL_U0["ref"] --, f0 <= 2.6e-8 m,
+    # velocity <= 1.9e-8 m/s, next CoM <= 2.4e-8 relative); rounds 2-3 held them at 2e-3 / 2e-5 / 5e-6
+    tol_u0 = 6e-5 if f32 else TOL_U0[backend]
+    tol_f0, tol_v = (6e-8, 4e-8) if f32 else (1e-7, 1e-6)
     phi, dA = np.pi / 4, 0.1
     if workload_name == "mc_C200":
         Cn, Pn = 200, 400
@@ -587,7 +590,7 @@ def test_full_batch_properties_and_oracle_sample(FA, workload_name, precision, s
         worst = dict(u0=max(worst["u0"], e_u0), f0=max(worst["f0"], e_f0), vel=max(worst["vel"], e_v), com_rel=max(worst["com_rel"], e_c))
         assert e_u0 <= tol_u0, (i, out["u0"][i], r["u0"])
         assert e_f0 <= tol_f0 and e_v <= tol_v, (i, e_f0, e_v)
-        assert e_c <= 1e-6, (i, e_c)                          # the north star's figure: next CoM, relative
+        assert e_c <= (6e-8 if f32 else 1e-6), (i, e_c)       # the north star's figure (1e-6): next CoM, relative; fp32 held at 2x its measured 2.4e-8
     _record_maxima(f"full_batch:{workload_name}:{precision}:stream{stream}:{backend}", dict(worst, sample=len(pick), tol_u0=tol_u0, tol_f0=tol_f0, tol_v=tol_v))
     gen.close()
 
@@ -631,6 +634,8 @@ def test_fp32_solve_against_fp64_and_oracle(FA, workload_name):
     rel = np.abs(com64 - com32).max(1) / np.maximum(np.abs(com64).max(1), 1e-3)
     assert rel.max() <= 1e-6, rel.max()
     assert np.abs(np.stack([s64["xd"], s64["yd"]], 1) - np.stack([s32["xd"], s32["yd"]], 1)).max() <= 5e-6
+    _record_maxima(f"fp32_vs_fp64:{workload_name}", dict(com_rel=rel.max(), vel=np.abs(np.stack([s64["xd"], s64["yd"]], 1) - np.stack([s32["xd"], s32["yd"]], 1)).max(),
+                                                        f0=np.abs(o64["f0"] - o32["f0"]).max(), u0=np.abs(o64["u0"] - o32["u0"]).max(), sample=B))
     assert np.abs(o64["f0"] - o32["f0"]).max() <= 2e-5 and np.abs(o64["u0"] - o32["u0"]).max() <= 2e-3
     assert np.array_equal(s64["fc"], s32["fc"]) and np.array_equal(s64["j"], s32["j"])               # counters bit exact
     # the fp32 result against the oracle
