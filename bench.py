@@ -525,6 +525,9 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
     if sweep_sets > 0:
         tick_in["reserved"] = (first + np.arange(B)) % sweep_sets
     d_in = q.to_device(tick_in, R.dev)
+    sweep_sorted = sweep_sets > 0 and os.environ.get("ISMPC_BENCH_SWEEP_BIND", "1") != "0"
+    if sweep_sorted:
+        solver.sweep_bind(d_in)        # once: a sweep's instance -> set assignment is static, the launches then run sorted by set (ismpc_sweep_bind)
     d_out = [torch.empty((B, 80), dtype=torch.uint8, device=R.dev) for _ in range(2)]
     cus = torch.cuda.get_device_properties(R.dev).multi_processor_count
     pipe, grp = None, None
@@ -568,6 +571,8 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
                     else q.MPCSolver(q.reference_plan(params=p), params=p, device=R.local_rank))
         finally:
             del os.environ["ISMPC_Z_FALLBACK"]
+        if sweep_sorted:
+            solo.sweep_bind(d_in)
     d_tmp = torch.empty_like(d_out[0])
     ev2 = RegionEvents(torch)
     timed_regions(R, lambda k: solo.solve_batch_torch(d_in, d_tmp), K, W, min_ms, ev=(ev2.start, ev2.end))
@@ -678,6 +683,7 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
         ng = (N + 63) // 64 * 64
         flops = info["mfma_gemm_launches"] * 2.0 * ng ** 3 * sweep_sets
         res["config"]["workload"] = res["config"]["workload"].replace("Formulation B (MPCSolver::solve)", f"Formulation B PARAMETER SWEEP ({sweep_sets} parameter sets: mass, h_des, q_p, q_u, q_v, foot width; instance i -> set i % {sweep_sets})")
+        res["config"]["sorted_by_set"] = bool(sweep_sorted)
         res["sweep"] = dict(info, mfma_flops=flops, build_tflops=flops / (info["build_ms"] * 1e-3) / 1e12 if info["build_ms"] > 0 else None,
                             note="tables of every set built on the device: Newton-Schulz inverse of the vertical Hessians as batched v_mfma_f64_16x16x4_f64 products "
                                  "(csrc/ismpc_sweep.hip); build_ms = the whole build (all kernels), build_tflops = the MFMA products' flops over it")

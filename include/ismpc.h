@@ -125,9 +125,19 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows,
  * Hessian MPCSolver.cpp:258 and the tables derived from it; for a sweep they are built ON THE DEVICE for all sets at
  * once -- Newton-Schulz inverse as batched dense products on v_mfma_f64_16x16x4_f64 (csrc/ismpc_sweep.hip).  An instance
  * names its set in ismpc_tick_in.reserved (0 <= reserved < n_sets; anything else: ISMPC_ST_BAD_INDEX, state passed
- * through).  Flat plans, N <= 128, F <= 16.  All entry points below work on a sweep handle.                              */
+ * through).  Any plan and any horizon a plain handle takes (N <= 256: the lane-group kernels up to 128, one instance per
+ * wavefront beyond; a plan with footsteps off z = 0 adds per-frame offset tables per set, also built on the device); F <= 16.
+ * All entry points below work on a sweep handle.                                                                      */
 int ismpc_create_sweep(const ismpc_params* params, int n_sets, const double* ftsp, int rows,
                        int device, ismpc_handle** out);
+/* Optional, for batches whose instance -> set assignment stays put from call to call (a sweep's usual shape): sorts the instances
+ * of the `batch` records at in_dev by their parameter set, once (a counting sort on the device; returns when done).  Later
+ * ismpc_solve_batch* calls of the SAME batch size then run instance order[g] in launch slot g, so that the lane groups of a
+ * wavefront read one set's tables, and hand each XCD (workgroup index mod 8) one contiguous eighth of the sorted batch: K / 8
+ * sets' tables per L2 instead of all K.  Only the placement of instances in the launch changes: every record is byte-identical
+ * with and without it, also when `reserved` has changed since (each instance still reads its own set; a stale order only costs
+ * the locality).  Rebind after changing the assignment or the batch size; batch = 0 unbinds.                                     */
+int ismpc_sweep_bind(ismpc_handle* h, int batch, const ismpc_tick_in* in_dev, void* stream);
 /* n_sets (1 for a plain handle), Newton-Schulz iterations run, batched MFMA product launches, table build time. */
 int ismpc_sweep_info(const ismpc_handle* h, int* n_sets, int* newton_iterations, int* mfma_gemm_launches, double* build_ms);
 /* The device-built tables of one set against the host's long-double build of the same parameters (what ismpc_create

@@ -32,7 +32,7 @@ EXPORTS = ["ismpc_params_default", "ismpc_create", "ismpc_destroy", "ismpc_solve
            "ismpc_solve_batch_device", "ismpc_rollout_device", "ismpc_abi_version", "ismpc_last_error",
            "ismpc_get_params", "ismpc_midpoint_rows", "ismpc_get_midpoint", "ismpc_set_timing",
            "ismpc_last_kernel_ms", "ismpc_reserve", "ismpc_host_alloc", "ismpc_host_free", "ismpc_host_register",
-           "ismpc_host_unregister", "ismpc_create_sweep", "ismpc_sweep_info", "ismpc_sweep_verify_tables", "ismpc_fallback_counters"]
+           "ismpc_host_unregister", "ismpc_create_sweep", "ismpc_sweep_info", "ismpc_sweep_verify_tables", "ismpc_fallback_counters", "ismpc_sweep_bind"]
 
 _lib = None
 
@@ -81,6 +81,7 @@ def load():
     lib.ismpc_sweep_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(cd)]; lib.ismpc_sweep_info.restype = ci
     lib.ismpc_sweep_verify_tables.argtypes = [vp, ci, vp]; lib.ismpc_sweep_verify_tables.restype = ci
     lib.ismpc_fallback_counters.argtypes = [vp, vp]; lib.ismpc_fallback_counters.restype = ci
+    lib.ismpc_sweep_bind.argtypes = [vp, ci, vp, vp]; lib.ismpc_sweep_bind.restype = ci
     _lib = lib
     return lib
 

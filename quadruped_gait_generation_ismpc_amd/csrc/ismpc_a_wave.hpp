@@ -209,7 +209,7 @@ __device__ __forceinline__ bool flag_of(float v) { return (__float_as_int(v) & 1
 __device__ __forceinline__ bool flag_of(double v) { return (__double_as_longlong(v) & 1ll) != 0; }
 
 #ifndef ISMPC_A_GCAP
-#define ISMPC_A_GCAP 8
+#define ISMPC_A_GCAP 64
 #endif
 constexpr int GCAP = ISMPC_A_GCAP;     // Gram sums of a block solve accumulated per pass (a power of two; 64 = all at once, as rounds 1-3 did)
 
@@ -768,6 +768,9 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #undef G_IN
 #undef G_AT
                                     }
+#ifdef ISMPC_A_GRAM_SCHED
+                                    __builtin_amdgcn_sched_barrier(0);       // one row's pair differences live at a time
+#endif
                                 }
                                 if constexpr (NP == GCAP) {
                                     const R part = fold_pow2<R, GCAP, 1>(acc, lane);

@@ -58,6 +58,10 @@ struct DevConst {
     const double *HSt, *SHSt;
     const DevConst* sets; int nsets;  // parameter sweeps (ismpc_create_sweep): one record per parameter set, its own tables and scalars; the
                                       // instance's record names its set (ismpc_tick_in.reserved).  NULL / 0 for a plain handle
+    const int* order;                 // sweeps, after ismpc_sweep_bind: the instances of the bound batch sorted by parameter set.  Slot g of the
+                                      // launch runs instance order[g], so the lane groups of a wavefront read ONE set's tables, and workgroup b
+                                      // takes the slots of virtual block sweep_vblock(b): the workgroups an XCD receives (b mod 8) cover one
+                                      // contiguous eighth of the sorted batch -- K / 8 sets' tables per L2 instead of all K.  NULL: slot g = instance g
     int* zflag;                       // four self-resetting counters (zeroed once, at ismpc_create): [0] entries in the deferred list of the
                                       // running two-launch step, [1] fallback workgroups done with it, [2] instances an in-kernel rollout
                                       // parked for its resume launch, [3] resume workgroups done.  The consumer launch exits at once on a
@@ -838,7 +842,8 @@ template <int R, bool FB>
 __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi, const int lane,
                                                  const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                                                  ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj,
-                                                 int rollout_frame, unsigned char* zmark, int launch_id, int* zlist = nullptr, int zbatch = 0, double* zlds = nullptr)
+                                                 int rollout_frame, unsigned char* zmark, int launch_id, int* zlist = nullptr, int zbatch = 0, double* zlds = nullptr,
+                                                 const int extra_status = 0)
 {
     constexpr int NT = ismpc::Tables::NT;
     const int N = c.N;
@@ -849,7 +854,7 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
     const double x0 = rec->com_pos[0], y0 = rec->com_pos[1], z0 = rec->com_pos[2];
     const double xd0 = rec->com_vel[0], yd0 = rec->com_vel[1], zd0 = rec->com_vel[2];
     int idx;
-    int status = gate_tick(c, w, idx);
+    int status = gate_tick(c, w, idx) | extra_status;       // (extra_status: a sweep instance that names no parameter set -- passed through)
     double o_x = x0, o_y = y0, o_z = z0, o_xd = xd0, o_yd = yd0, o_zd = zd0;
     double uz0 = 0.0, ux0 = 0.0, uy0 = 0.0;
     int itx = 0, ity = 0, zits = 0;
@@ -1121,7 +1126,9 @@ __device__ __forceinline__ void tick_affine_body(const DevConst& c, const int gi
 #ifndef ISMPC_AFF_WAVES
 #define ISMPC_AFF_WAVES 4
 #endif
-template <int R>
+// SW: a parameter-sweep handle at a horizon the lane-group kernels do not cover (128 < N <= 256): one instance per wavefront, so the
+// instance's parameter set is wave-uniform and the body runs on that set's own record (tables and scalars), as the fallback launch does.
+template <int R, bool SW = false>
 __global__ __launch_bounds__(64 * ISMPC_AFF_WAVES) __attribute__((amdgpu_num_sgpr(80)))
 void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
                        ismpc_tick_out* __restrict__ out, double* __restrict__ u_traj, int batch, int rollout_frame,
@@ -1130,6 +1137,12 @@ void ismpc_tick_affine(const DevConst c, const ismpc_tick_in* __restrict__ in_ro
     const int lane = threadIdx.x & 63;
     const int gi = blockIdx.x * ISMPC_AFF_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (gi >= batch) return;
+    if constexpr (SW) {
+        const int ps = __builtin_amdgcn_readfirstlane((((rollout_frame >= 0) ? state_rw : in_ro) + gi)->reserved);
+        const bool known = ps >= 0 && ps < c.nsets;                  // an unknown set: ISMPC_ST_BAD_INDEX, state passed through
+        tick_affine_body<R, false>(c.sets[known ? ps : 0], gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id,
+                                   zmark ? zlist_of(zmark, batch) : nullptr, batch, nullptr, known ? 0 : ISMPC_ST_BAD_INDEX);
+    } else
     tick_affine_body<R, false>(c, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, zmark ? zlist_of(zmark, batch) : nullptr, batch);
 }
 
@@ -1376,16 +1389,16 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
         int nemax = 0;
 #pragma unroll
         for (int g = 0; g < 64; g += LPI) nemax = max(nemax, __builtin_amdgcn_readlane(ne, g));
-        const double* dUr = c.dU + (size_t)idx * NT;
-        const double* sUr = c.SdU + (size_t)idx * NT;
+        const double* dUr = (SW ? P->dU : c.dU) + (size_t)idx * NT;          // (a sweep: this instance's set has its own offsets and corrections)
+        const double* sUr = (SW ? P->SdU : c.SdU) + (size_t)idx * NT;
         double du[R], ds[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { du[r] = dUr[n0 + r]; ds[r] = sUr[n0 + r]; }
         for (int e = 0; e < nemax; ++e) {
             const bool on = e < ne;
             const double ue = on ? dUr[elo + e] : 0.0;
-            const double* wr = c.Wt + ((size_t)pp * c.Fmax + (on ? e : 0)) * NT + n0;
-            const double* sr = c.SW + ((size_t)pp * c.Fmax + (on ? e : 0)) * NT + n0;
+            const double* wr = (SW ? P->Wt : c.Wt) + ((size_t)pp * c.Fmax + (on ? e : 0)) * NT + n0;
+            const double* sr = (SW ? P->SW : c.SW) + ((size_t)pp * c.Fmax + (on ? e : 0)) * NT + n0;
 #pragma unroll
             for (int r = 0; r < R; ++r) { du[r] = fma(-wr[r], ue, du[r]); ds[r] = fma(-sr[r], ue, ds[r]); }
         }
@@ -1434,6 +1447,10 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
                 ch1[r] = wv * Q; s1[r] = s1[r] * P; s2[r] = le_[r] * s1[r];
             }
         } else {
+            // some group of this wavefront needs the long polynomial.  The choice is made PER GROUP (= per instance): a group whose own
+            // samples all have w <= 0.004 takes the degree-3 values here too, so an instance's record does not depend on which instances
+            // share its wavefront (round 4: a sweep sorted by parameter set, ismpc_sweep_bind, changes an instance's wave-mates)
+            const bool gmid = ((__builtin_amdgcn_ballot_w64(mid) >> (lane & (64 - LPI))) & ((LPI == 64) ? ~0ull : ((1ull << LPI) - 1ull))) != 0ull;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const double wv = wv_[r], dtn = s1[r];
@@ -1441,7 +1458,7 @@ __device__ __forceinline__ bool tick_group_core(const DevConst& c, const int lan
                 P = fma(P, wv, 1.0 / 6227020800.0);  Q = fma(Q, wv, 1.0 / 87178291200.0);
                 P = fma(P, wv, 1.0 / 39916800.0);    Q = fma(Q, wv, 1.0 / 479001600.0);
                 P = fma(P, wv, 1.0 / 362880.0);      Q = fma(Q, wv, 1.0 / 3628800.0);
-                P = fma(P, wv, 1.0 / 5040.0);        Q = fma(Q, wv, 1.0 / 40320.0);
+                P = gmid ? fma(P, wv, 1.0 / 5040.0) : 1.0 / 5040.0;   Q = gmid ? fma(Q, wv, 1.0 / 40320.0) : 1.0 / 40320.0;   // (degree 3 starts here)
                 P = fma(P, wv, 1.0 / 120.0);         Q = fma(Q, wv, 1.0 / 720.0);
                 P = fma(P, wv, 1.0 / 6.0);           Q = fma(Q, wv, 1.0 / 24.0);
                 P = fma(P, wv, 1.0);                 Q = fma(Q, wv, 0.5);
@@ -1674,6 +1691,19 @@ __device__ __forceinline__ bool tick_group_body(const DevConst& c, const int gi_
 #ifndef ISMPC_QUAD_WAVES
 #define ISMPC_QUAD_WAVES 4
 #endif
+// Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b mod 8, each with its own L2).  The virtual block of
+// workgroup b: XCD x takes the contiguous range [x q + min(x, r), ...) of the nb blocks (q = nb / 8, r = nb mod 8) -- a bijection.
+__device__ __forceinline__ int sweep_vblock(int b, int nb)
+{
+    const int q = nb >> 3, r = nb & 7, x = b & 7;
+    return x * q + min(x, r) + (b >> 3);
+}
+// instance of launch slot `slot` (see DevConst::order); slots past the batch name no instance
+template <bool SW> __device__ __forceinline__ int slot_instance(const DevConst& c, int slot, int batch)
+{
+    if (SW) { if (c.order) return slot < batch ? c.order[slot] : batch; }
+    return slot;
+}
 template <int R, int LPI, bool SW = false>
 __global__ __launch_bounds__(64 * ISMPC_QUAD_WAVES)
 void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, ismpc_tick_in* state_rw,
@@ -1684,9 +1714,10 @@ void ismpc_tick_quad(const DevConst c, const ismpc_tick_in* __restrict__ in_ro, 
     __shared__ double2 lds_mid[ISMPC_QUAD_WAVES][wave_lds_double2<R, LPI>()];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
+    const int blk = (SW && c.order) ? sweep_vblock(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int wave = blk * ISMPC_QUAD_WAVES + wv;
     if (wave * IPW >= batch) return;
-    tick_group_body<R, LPI, ISMPC_KF_MAIN, SW>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv],
+    tick_group_body<R, LPI, ISMPC_KF_MAIN, SW>(c, slot_instance<SW>(c, wave * IPW + lane / LPI, batch), batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv],
                                                zmark ? zlist_of(zmark, batch) : nullptr);
 }
 
@@ -1751,15 +1782,16 @@ void ismpc_tick_quad_one(const DevConst c, const ismpc_tick_in* __restrict__ in_
     __shared__ double2 lds_mid[ISMPC_QUAD_WAVES][wave_lds_double2_fb<R, LPI>()];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wave = blockIdx.x * ISMPC_QUAD_WAVES + wv;
+    const int blk = (SW && c.order) ? sweep_vblock(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int wave = blk * ISMPC_QUAD_WAVES + wv;
     if (wave * IPW >= batch) return;
-    const bool def = tick_group_body<R, LPI, ISMPC_KF_MAIN, SW>(c, wave * IPW + lane / LPI, batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
+    const bool def = tick_group_body<R, LPI, ISMPC_KF_MAIN, SW>(c, slot_instance<SW>(c, wave * IPW + lane / LPI, batch), batch, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, lds_mid[wv]);
     unsigned long long m = __builtin_amdgcn_ballot_w64(def);
     if (m == 0ull) return;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     for (int q = 0; q < IPW; ++q)
         if ((m >> (LPI * q)) & 1ull) {
-            const int gi = wave * IPW + q;
+            const int gi = __builtin_amdgcn_readfirstlane(slot_instance<SW>(c, wave * IPW + q, batch));
             const DevConst* cp = cdev;
             if (SW) cp = c.sets + __builtin_amdgcn_readfirstlane((((rollout_frame >= 0) ? state_rw : in_ro) + gi)->reserved);   // (a deferred instance has a valid set)
             fallback_call_one<RW, one_occ<R, SW>()>(cp, gi, lane, in_ro, state_rw, out, u_traj, rollout_frame, zmark, launch_id, reinterpret_cast<double*>(lds_mid[wv]));
@@ -1887,6 +1919,36 @@ void ismpc_tick_affine_fallback(const DevConst c, const ismpc_tick_in* __restric
     if (threadIdx.x == 0 && atomicAdd(c.zflag + 1, 1) == (int)gridDim.x - 1) { c.zflag[0] = 0; c.zflag[1] = 0; __threadfence(); }
 }
 
+// ---- ismpc_sweep_bind: counting sort of the instances of a batch by parameter set (bucket nsets: records that name no set) ----------
+__global__ __launch_bounds__(256) void sweep_sort_hist(const ismpc_tick_in* __restrict__ in, int batch, int nsets, int* __restrict__ counts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    const int ps = in[i].reserved;
+    atomicAdd(counts + ((ps >= 0 && ps < nsets) ? ps : nsets), 1);
+}
+// exclusive scan of counts[0 .. n) in place (one workgroup; n <= 65 536 + 1): counts[k] becomes the first slot of bucket k
+__global__ __launch_bounds__(256) void sweep_sort_scan(int* __restrict__ counts, int n)
+{
+    __shared__ int part[256];
+    const int tid = threadIdx.x, per = (n + 255) / 256, lo = tid * per, hi = min(lo + per, n);
+    int s = 0;
+    for (int k = lo; k < hi; ++k) s += counts[k];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int k = 0; k < 256; ++k) { const int v = part[k]; part[k] = run; run += v; } }
+    __syncthreads();
+    int run = part[tid];
+    for (int k = lo; k < hi; ++k) { const int v = counts[k]; counts[k] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void sweep_sort_scatter(const ismpc_tick_in* __restrict__ in, int batch, int nsets, int* __restrict__ cursor, int* __restrict__ order)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    const int ps = in[i].reserved;
+    order[atomicAdd(cursor + ((ps >= 0 && ps < nsets) ? ps : nsets), 1)] = i;      // (the order INSIDE a bucket is whatever the atomics give: no result depends on it)
+}
+
 // ------------------------------------------------------------------------
 // Entry points run on the handle's device and leave the caller's current device as they found it (a torch process that
 // drives several GPUs keeps allocating where it was).
@@ -1937,6 +1999,7 @@ struct ismpc_handle {
     DevConst* c_dev = nullptr;    // the constants in device memory (the one-launch kernel's fallback call reads them there)
     bool sweep = false;           // ismpc_create_sweep: K parameter sets, tables built on the device (csrc/ismpc_sweep.hip)
     ismpc::SweepSlabs sw; std::vector<ismpc_params> sets; std::vector<double> ftsp;   // (the plan as given: ismpc_sweep_verify_tables rebuilds a set on the host)
+    int* order = nullptr; int order_cap = 0, order_batch = 0;   // ismpc_sweep_bind: instances of the bound batch sorted by parameter set (+ nsets + 1 bucket cursors)
     hipStream_t last_stream = nullptr; bool used = false;   // stream of the previous launch: zmark / zstop outlive a call and are re-allocated
                                                             // only after that stream has drained (grow_sync)
 };
@@ -2051,6 +2114,7 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
             if (h->sweep) {
                 // parameter sweep: the per-tick kernel reads each instance's set through c.sets (16 lanes per instance, 8 beyond LPI16_BATCH)
                 if (lpi == 8) cq.sets = h->sets8;
+                cq.order = (h->order && h->order_batch == batch && rollout_frame < 0) ? h->order : nullptr;     // (ismpc_sweep_bind; per-tick launches only)
 #define ISMPC_SWEEP_SHAPES(X) \
     if (lpi == 16) { if (RQ == 4) X(4, 16, 1); else if (RQ == 7) X(7, 16, 2); else X(8, 16, 2); } \
     else           { if (RQ == 8) X(8, 8, 1);   else if (RQ == 13) X(13, 8, 2); else X(16, 8, 2); }
@@ -2098,8 +2162,13 @@ int launch(ismpc_handle* h, int batch, const ismpc_tick_in* in, ismpc_tick_in* s
             return ISMPC_OK;
         }
 #define ISMPC_AFF(RR) do { \
+        if (h->sweep) { \
+            hipLaunchKernelGGL((ismpc_tick_affine<RR, true>), dim3((batch + ISMPC_AFF_WAVES - 1) / ISMPC_AFF_WAVES), dim3(64 * ISMPC_AFF_WAVES), 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); \
+            if (zm) hipLaunchKernelGGL((ismpc_tick_affine_fallback<RR, true>), fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); \
+        } else { \
         hipLaunchKernelGGL(ismpc_tick_affine<RR>, dim3((batch + ISMPC_AFF_WAVES - 1) / ISMPC_AFF_WAVES), dim3(64 * ISMPC_AFF_WAVES), 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); \
         if (zm) hipLaunchKernelGGL(ismpc_tick_affine_fallback<RR>, fgrid, block, 0, s, h->c, in, state, out, u_traj, batch, rollout_frame, zm, lid); \
+        } \
     } while (0)
         switch (R) {
             case 1: ISMPC_AFF(1); break;
@@ -2291,7 +2360,7 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
         // wavefront reading eight sets' tables it measured level to 2 % slower on the 64-set batch (9.25-9.28 against 9.27-9.43e8 ticks/s)
         const char* lp8 = std::getenv("ISMPC_LPI");
         const bool lanes8 = lp8 && std::atoi(lp8) == 8;
-        rc = ismpc::sweep_build(params, K, h->t, c.midx, c.midy, c.e_lo, c.ne, 16, quad_R(t.p.N, 16), lanes8 ? 8 : 0, quad_R(t.p.N, 8), h->own_stream, h->sw, h->dev_allocs, serr);
+        rc = ismpc::sweep_build(params, K, h->t, c.midx, c.midy, c.midz, c.e_lo, c.ne, 16, quad_R(t.p.N, 16), lanes8 ? 8 : 0, quad_R(t.p.N, 8), h->own_stream, h->sw, h->dev_allocs, serr);
         if (rc != ISMPC_OK) { ismpc_destroy(h); return fail(rc, serr); }
         std::vector<DevConst> cs((size_t)K, h->c);
         for (int k = 0; k < K; ++k) {
@@ -2303,6 +2372,7 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
             d.vtab = h->sw.vtab + (size_t)k * h->sw.s_vtab; d.vqT = h->sw.vqT + (size_t)k * h->sw.s_vqT;
             d.Wt = h->sw.Wt + (size_t)k * h->sw.s_W; d.SW = h->sw.SW + (size_t)k * h->sw.s_W;
             d.HSt = h->sw.HSt + (size_t)k * h->sw.s_HS; d.SHSt = h->sw.SHSt + (size_t)k * h->sw.s_HS;
+            if (h->sw.dU) { d.dU = h->sw.dU + (size_t)k * h->sw.s_dU; d.SdU = h->sw.SdU + (size_t)k * h->sw.s_dU; }      // (plans with mid_z != 0)
             d.tailx = h->sw.tailx + (size_t)k * h->sw.s_tail; d.taily = h->sw.taily + (size_t)k * h->sw.s_tail;
             d.Hinv = nullptr; d.W = nullptr; d.vq = nullptr; d.sets = nullptr; d.nsets = 0;
         }
@@ -2338,6 +2408,33 @@ int ismpc_create(const ismpc_params* params, const double* ftsp, int rows, int d
 int ismpc_create_sweep(const ismpc_params* params, int n_sets, const double* ftsp, int rows, int device, ismpc_handle** out)
 {
     return create_impl(params, n_sets, true, ftsp, rows, device, out);
+}
+
+int ismpc_sweep_bind(ismpc_handle* h, int batch, const ismpc_tick_in* in_dev, void* stream)
+{
+    if (!h || batch < 0 || (batch > 0 && !in_dev)) return fail(ISMPC_E_INVALID, "bad argument");
+    if (!h->sweep) return fail(ISMPC_E_INVALID, "ismpc_sweep_bind needs a handle of ismpc_create_sweep");
+    ON_DEVICE(h);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (batch == 0) { h->order_batch = 0; return ISMPC_OK; }
+    const int nb = h->c.nsets + 1;
+    if (batch + nb > h->order_cap) {
+        HIP_TRY(hipDeviceSynchronize());                       // (a set-up call: launches that still read the old order finish first)
+        if (h->order) HIP_TRY(hipFree(h->order));
+        h->order = nullptr; h->order_cap = 0; h->order_batch = 0;
+        HIP_TRY(hipMalloc((void**)&h->order, sizeof(int) * (size_t)(batch + nb)));
+        h->order_cap = batch + nb;
+    }
+    int* cursor = h->order + batch;
+    HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)nb, s));
+    const dim3 grid((batch + 255) / 256), block(256);
+    hipLaunchKernelGGL(sweep_sort_hist, grid, block, 0, s, in_dev, batch, h->c.nsets, cursor);
+    hipLaunchKernelGGL(sweep_sort_scan, dim3(1), block, 0, s, cursor, nb);
+    hipLaunchKernelGGL(sweep_sort_scatter, grid, block, 0, s, in_dev, batch, h->c.nsets, cursor, h->order);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    h->order_batch = batch;
+    return ISMPC_OK;
 }
 
 int ismpc_sweep_info(const ismpc_handle* h, int* n_sets, int* newton_iterations, int* mfma_gemm_launches, double* build_ms)
@@ -2405,6 +2502,7 @@ void ismpc_destroy(ismpc_handle* h)
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->zmark) (void)hipFree(h->zmark);
+    if (h->order) (void)hipFree(h->order);
     if (h->zstop) (void)hipFree(h->zstop);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

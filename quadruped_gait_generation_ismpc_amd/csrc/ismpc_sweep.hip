@@ -278,6 +278,39 @@ __global__ __launch_bounds__(256) void sweep_patterns(const double* __restrict__
     }
 }
 
+// ---- plans with mid_z != 0 (MPCSolver.cpp:259: f_z carries q_p S' mid_z[idx : idx + N]): per frame idx the offset of the unconstrained
+// minimiser dU(idx) = Hinv q_p S' w = q_p sum_k w_k (Hinv S_k'), w = the window -- a combination of the rows of the fallback table HSt,
+// which this set already has -- and S dU(idx) (ismpc_tables.cpp "if (!t.flat)").  One workgroup per (frame, set); frames whose window is
+// all zero keep the zero the slab was cleared to.
+__global__ __launch_bounds__(256) void sweep_du(const double* __restrict__ par, const double* __restrict__ midz, int nmid, const double* __restrict__ HSt, size_t s_HS,
+                                                double* __restrict__ dU, double* __restrict__ SdU, size_t s_dU, int N, double dt)
+{
+    __shared__ double win[256], du[256];
+    __shared__ int any;
+    const int idx = blockIdx.x, set = blockIdx.y, tid = threadIdx.x;
+    if (idx + 2 * N > nmid) return;
+    if (tid == 0) any = 0;
+    __syncthreads();
+    if (tid < N) { win[tid] = midz[idx + tid]; if (win[tid] != 0.0) any = 1; }
+    __syncthreads();
+    if (!any) return;
+    const double mass = par[set * PAR + 0], q_p = par[set * PAR + 1];
+    const double cs = dt * dt / mass;
+    const double* hs = HSt + (size_t)set * s_HS;
+    if (tid < N) {
+        double acc = 0.0;
+        for (int k = 0; k < N; ++k) acc = fma(win[k], hs[(size_t)k * NT + tid], acc);
+        du[tid] = q_p * acc;
+        dU[(size_t)set * s_dU + (size_t)idx * NT + tid] = du[tid];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        DD c1 = {0.0, 0.0}, c2 = {0.0, 0.0};
+        double* o = SdU + (size_t)set * s_dU + (size_t)idx * NT;
+        for (int k = 0; k < N; ++k) { o[k] = cs * (c2.hi + c2.lo); dd_add(c1, du[k]); dd_add(c2, c1); }
+    }
+}
+
 // ---- vtab -> vqT (lane-contiguous copy for the lane-group kernels; ismpc_hip.hip)
 __global__ __launch_bounds__(256) void sweep_layout(const double* __restrict__ vtab, size_t s_vtab, double* __restrict__ vqT, size_t s_vqT, int lpi, int R)
 {
@@ -344,14 +377,13 @@ int dalloc(double** p, size_t n, std::vector<void*>& allocs, std::string& err)
 
 }  // namespace
 
-int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double* midx_dev, const double* midy_dev, const int* e_lo_dev,
+int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double* midx_dev, const double* midy_dev, const double* midz_dev, const int* e_lo_dev,
                 const int* ne_dev, int lpi, int R, int lpi2, int R2, hipStream_t s, SweepSlabs& o, std::vector<void*>& allocs, std::string& err)
 {
     const int N = t0.p.N;
     if (K < 1) { err = "a sweep needs at least one parameter set"; return ISMPC_E_INVALID; }
-    if (N > 128) { err = "parameter sweeps cover horizons N <= 128 (the lane-group kernels)"; return ISMPC_E_UNSUPPORTED; }
+    if (N > 256) { err = "parameter sweeps cover horizons N <= 256"; return ISMPC_E_UNSUPPORTED; }       // (beyond 128: one instance per wavefront, ismpc_tick_affine<R, true>)
     if (t0.Fmax > FMAX_SWEEP) { err = "parameter sweeps cover F <= 16 double-support samples"; return ISMPC_E_UNSUPPORTED; }
-    if (!t0.flat) { err = "parameter sweeps need a flat plan (every footstep at z = 0, as Controller.cpp:89-97 builds it)"; return ISMPC_E_UNSUPPORTED; }
     const int NG = (N + 63) / 64 * 64;
     const double dt = t0.p.mpc_dt;
     o.K = K; o.NG = NG;
@@ -389,6 +421,12 @@ int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double*
     SW_TRY(hipMemsetAsync(o.SW, 0, (size_t)K * o.s_W * sizeof(double), s));
     SW_TRY(hipMemsetAsync(o.HSt, 0, (size_t)K * o.s_HS * sizeof(double), s));
     SW_TRY(hipMemsetAsync(o.SHSt, 0, (size_t)K * o.s_HS * sizeof(double), s));
+    if (!t0.flat) {
+        o.s_dU = (size_t)t0.nmid * NT;
+        if ((rc = dalloc(&o.dU, (size_t)K * o.s_dU, allocs, err)) || (rc = dalloc(&o.SdU, (size_t)K * o.s_dU, allocs, err))) return rc;
+        SW_TRY(hipMemsetAsync(o.dU, 0, (size_t)K * o.s_dU * sizeof(double), s));
+        SW_TRY(hipMemsetAsync(o.SdU, 0, (size_t)K * o.s_dU * sizeof(double), s));
+    }
     struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev;
     SW_TRY(hipEventCreate(&ev.a)); SW_TRY(hipEventCreate(&ev.b));
     hipEvent_t e0 = ev.a, e1 = ev.b;
@@ -415,6 +453,8 @@ int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double*
     hipLaunchKernelGGL((sweep_gemm<2>), ggrid, dim3(256), 0, s, (const double*)o.Ut, (size_t)0, (const double*)o.M1, o.s_mat, o.SHSt, o.s_HS, (const double*)o.par, 1, NG, N);
     launches += 4;
     hipLaunchKernelGGL(sweep_transpose_nt, dim3(16, K), dim3(256), 0, s, (const double*)o.M1, o.s_mat, o.HSt, o.s_HS, N, NG);
+    if (!t0.flat)
+        hipLaunchKernelGGL(sweep_du, dim3(t0.nmid, K), dim3(256), 0, s, (const double*)o.par, midz_dev, t0.nmid, (const double*)o.HSt, o.s_HS, o.dU, o.SdU, o.s_dU, N, dt);
     hipLaunchKernelGGL(sweep_hvec, dim3(K), dim3(256), 0, s, (const double*)o.par, (const double*)o.X0, (const double*)o.H, o.s_mat, o.hvec, N, NG, dt);
     hipLaunchKernelGGL(sweep_patterns, dim3(t0.npat + 1, K), dim3(256), 0, s, (const double*)o.par, (const double*)o.X0, o.s_mat, (const double*)o.hvec,
                        e_lo_dev, ne_dev, t0.npat, t0.Fmax, o.vtab, o.s_vtab, o.Wt, o.SW, o.s_W, N, NG, dt);

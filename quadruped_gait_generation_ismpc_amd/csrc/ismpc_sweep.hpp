@@ -29,6 +29,7 @@ struct SweepSlabs {                 // one device slab per table kind, set k at 
     double *hvec = nullptr;         // 3 x NG per set: Hinv f0, Hinv fa, Hinv fb
     double *vtab = nullptr, *vqT = nullptr, *Wt = nullptr, *SW = nullptr, *HSt = nullptr, *SHSt = nullptr, *tailx = nullptr, *taily = nullptr;
     double* vqT2 = nullptr; size_t s_vqT2 = 0;   // the second lane-group layout of vtab (lpi2 / R2; null without one)
+    double *dU = nullptr, *SdU = nullptr; size_t s_dU = 0;   // plans with mid_z != 0 only: nmid x NT per set (sweep_du)
     size_t s_mat = 0, s_vtab = 0, s_vqT = 0, s_W = 0, s_HS = 0, s_tail = 0;   // strides (doubles)
     double* par = nullptr;          // K x 8: mass, q_p, q_u, q_v, h_des, eta, 1 / bound(|H|_inf), g
     int newton_iters = 0, gemm_launches = 0;
@@ -36,10 +37,11 @@ struct SweepSlabs {                 // one device slab per table kind, set k at 
     double max_residual = 0.0;      // max over the sets of |I - H X| (checked by sweep_build: a set above 1e-3 fails the build)
 };
 
+// (a plan with mid_z != 0 adds the per-frame offsets dU, SdU of every set: sweep_du)
 // Builds every per-set table on `stream` (synchronises before returning).  `t0` = host tables of set 0 (plan, patterns, structure).
 // lpi / R: lane-group layout of vqT (ismpc_hip.hip quad_R); lpi2 / R2: a second layout beside it (vqT2; lpi2 = 0: none).  All device
 // memory is appended to `allocs`.
-int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double* midx_dev, const double* midy_dev, const int* e_lo_dev,
+int sweep_build(const ismpc_params* sets, int K, const Tables& t0, const double* midx_dev, const double* midy_dev, const double* midz_dev, const int* e_lo_dev,
                 const int* ne_dev, int lpi, int R, int lpi2, int R2, hipStream_t stream, SweepSlabs& out, std::vector<void*>& allocs, std::string& err);
 
 }  // namespace ismpc

@@ -118,6 +118,16 @@ class MPCSolver:
         self._check(self._lib.ismpc_sweep_info(self._h, C.byref(n), C.byref(it), C.byref(gl), C.byref(ms)))
         return {"n_sets": n.value, "newton_iterations": it.value, "mfma_gemm_launches": gl.value, "build_ms": ms.value}
 
+    def sweep_bind(self, tick_in_u8):
+        """ismpc_sweep_bind on a CUDA uint8 tensor [batch, 72]: later calls of the same batch size run sorted by parameter set."""
+        import torch
+        assert tick_in_u8.is_cuda and tick_in_u8.dtype == torch.uint8 and tick_in_u8.shape[1] == 72 and tick_in_u8.is_contiguous()
+        s_ = torch.cuda.current_stream(tick_in_u8.device).cuda_stream
+        self._check(self._lib.ismpc_sweep_bind(self._h, int(tick_in_u8.shape[0]), C.c_void_p(tick_in_u8.data_ptr()), C.c_void_p(s_) if s_ else None))
+
+    def sweep_unbind(self):
+        self._check(self._lib.ismpc_sweep_bind(self._h, 0, None, None))
+
     def sweep_verify_tables(self, k):
         """max |device - host long double| / max |host| per table kind of parameter set k (ismpc_sweep_verify_tables)."""
         e = np.zeros(8)

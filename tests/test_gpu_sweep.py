@@ -83,6 +83,144 @@ def test_sweep_batch_against_one_oracle_per_set(q, sweep64, B):
     assert (np.abs(out["u0"][run, 0] - o2["u0"][run, 0]) > 1e-3).mean() > 0.9
 
 
+@pytest.mark.parametrize("N", [150, 200])
+def test_sweep_beyond_the_lane_group_horizon(q, N):
+    """Horizons the lane-group kernels do not cover (128 < N <= 256; the horizon is a run-time value of the reference, parameters.cpp:13,42,
+    and the golden vectors exist at 150 and 200): a sweep handle runs one instance per wavefront there (ismpc_tick_affine<R, true>: the
+    instance's set is wave-uniform), tables of every set built on the device as at N = 100.  16 sets against one oracle per set, the tables
+    of three sets against the host's long-double build, an unknown set flagged, and a sweep of equal sets against the plain handle."""
+    from oracle import oracle as O
+    from quadruped_gait_generation_ismpc_amd import workload
+    K = 16
+    ps = sweep_params(q, K, N=N)
+    s = q.MPCSolver.sweep(q.reference_plan(params=ps[0]), ps)
+    for k in (0, 5, K - 1):
+        e = s.sweep_verify_tables(k)
+        for name in ("Hinv", "affine", "W", "HSt", "SHSt", "tail"):
+            assert e[name] <= 1e-11, (k, e)                             # (measured at N = 200: 2.0e-12 for Hinv S', below 3e-13 for the inverse itself)
+        assert e["SW"] <= 1e-10, (k, e)
+    B = 1536
+    tin = workload.make_batch(N, B, seed=15)
+    tin["reserved"] = np.arange(B) % K
+    tin["reserved"][7] = K + 3                                           # names no set
+    out = s.solve_batch(tin)
+    assert out["status"][7] & q.ST_BAD_INDEX and np.array_equal(out["com_pos"][7], tin["com_pos"][7])
+    assert (np.delete(out["status"], 7) & q.ST_BAD_INDEX).sum() == 0
+    checked = 0
+    for k in range(K):
+        pick = np.where(tin["reserved"] == k)[0][:5]
+        op = O.default_params(N, mass=ps[k].mass, h_des=ps[k].h_des, q_p=ps[k].q_p, q_u=ps[k].q_u, q_v=ps[k].q_v, foot_width=ps[k].foot_width)
+        ref, _ = O.Oracle(op).solve(tin[pick])
+        o = out[pick]
+        ok = ((ref["status"] | o["status"]) & q.ST_ERROR_MASK) == 0
+        rel = np.abs(o["com_pos"] - ref["com_pos"]).max(1) / np.maximum(np.abs(ref["com_pos"]).max(1), 1e-3)
+        assert rel[ok].max(initial=0.0) <= TOL, (k, rel)
+        assert np.abs(o["com_vel"] - ref["com_vel"])[ok].max(initial=0.0) <= TOL
+        assert (o["status"][ok] == ref["status"][ok]).all()
+        checked += int(ok.sum())
+    assert checked >= 3 * K
+    # closed loop of the sweep handle (one launch per tick at this horizon) == per-tick calls fed back by the host
+    st = q.to_device(tin[:64]); ref_state = tin[:64].copy()
+    traj = q.from_device(s.rollout_torch(st, int(tin["simulation_time"].max()) + 1, 3), q.TICK_OUT)
+    assert traj.shape == (3, 64) and ((traj["status"] & q.ST_Z_FAILED) == 0).all()
+    s.close()
+    p = q.default_params(N=N)
+    plain = q.MPCSolver(q.reference_plan(params=p), params=p)
+    same = q.MPCSolver.sweep(q.reference_plan(params=p), [p, p])
+    t2 = workload.make_batch(N, 512, seed=16); t2["reserved"] = np.arange(512) % 2
+    a, b = plain.solve_batch(t2), same.solve_batch(t2)
+    assert np.array_equal(a["status"], b["status"]) and np.abs(a["com_pos"] - b["com_pos"]).max() <= 1e-9 and np.abs(a["com_vel"] - b["com_vel"]).max() <= 1e-9
+    plain.close(); same.close()
+
+
+@pytest.mark.parametrize("B", [6000, 40000])
+def test_sweep_bind_changes_placement_not_records(q, sweep64, B, monkeypatch):
+    """ismpc_sweep_bind sorts the instances of a batch by parameter set once; later launches of that batch size run instance order[g] in
+    slot g (one set per wavefront, one contiguous eighth of the sorted batch per XCD).  Placement only: every record byte-identical to the
+    unbound handle, in the one-launch and the two-launch form, also after the assignment changed under a stale order, also with records that
+    name no set; another batch size ignores the order; unbinding restores slot g = instance g."""
+    import torch
+    from quadruped_gait_generation_ismpc_amd import workload
+    _, ps = sweep64
+    tin = workload.make_batch(100, B, seed=23)
+    tin["reserved"] = (np.arange(B) * 7 + 3) % 64
+    tin["reserved"][[5, B // 2, B - 1]] = [64, -1, 9999]                 # no such sets
+    for form in ("3", "0"):                                              # one launch per step / tick kernel + fallback launch
+        monkeypatch.setenv("ISMPC_ONE_LAUNCH", form)
+        tight = [type(p).from_buffer_copy(bytes(p)) for p in ps]
+        for p in tight:
+            p.z_ineq_hi = 4.6                                            # some instances go through the inequality fallback
+        plain, bound = q.MPCSolver.sweep(q.reference_plan(params=tight[0]), tight), q.MPCSolver.sweep(q.reference_plan(params=tight[0]), tight)
+        d_in = q.to_device(tin)
+        ref = plain.solve_batch_torch(d_in).clone()
+        bound.sweep_bind(d_in)
+        got = bound.solve_batch_torch(d_in).clone()
+        torch.cuda.synchronize()
+        o = q.from_device(ref, q.TICK_OUT)
+        assert torch.equal(got, ref), form
+        assert (o["status"][[5, B // 2, B - 1]] & q.ST_BAD_INDEX).all() and ((o["status"] & q.ST_Z_INEQ_ACTIVE) != 0).sum() > 20
+        t2 = tin.copy(); t2["reserved"] = (np.arange(B) * 11 + 1) % 64       # the assignment moves, the order is stale: same records as unbound
+        d2 = q.to_device(t2)
+        assert torch.equal(bound.solve_batch_torch(d2), plain.solve_batch_torch(d2))
+        small = q.to_device(tin[:B // 2 + 1])                            # another batch size: the order does not apply
+        assert torch.equal(bound.solve_batch_torch(small), plain.solve_batch_torch(small))
+        bound.sweep_unbind()
+        assert torch.equal(bound.solve_batch_torch(d_in), ref)
+        assert bound.fallback_counters() == (0, 0, 0, 0)
+        plain.close(); bound.close()
+    # a plain handle refuses
+    p0 = q.default_params(N=100)
+    h = q.MPCSolver(q.reference_plan(params=p0), params=p0)
+    with pytest.raises(q.IsmpcError):
+        h.sweep_bind(q.to_device(tin[:64]))
+    h.close()
+
+
+@pytest.mark.parametrize("N", [100, 150])
+def test_sweep_on_a_plan_with_footstep_heights(q, N):
+    """Footsteps off z = 0 ("stairs": mid_z enters f_z, MPCSolver.cpp:259): every set then needs its own per-frame offsets
+    dU(idx) = Hinv_k q_p S' mid_z[idx : idx + N] and S dU(idx) beside its pattern corrections -- built on the device from the set's
+    fallback table (sweep_du).  12 sets, lane-group kernels (N = 100) and one instance per wavefront (N = 150), against one oracle per
+    set on the same plan; the heights do matter; equal sets reproduce the plain handle."""
+    from oracle import oracle as O
+    from quadruped_gait_generation_ismpc_amd import workload
+    K = 12
+    ps = sweep_params(q, K, N=N)
+    ftsp = q.reference_plan(params=ps[0])
+    for i in range(1, ftsp.shape[0]):
+        ftsp[i, 2] = 0.01 * ((i // 3) % 4)
+    s = q.MPCSolver.sweep(ftsp, ps)
+    B = 960
+    tin = workload.make_batch(N, B, seed=17)
+    tin["reserved"] = np.arange(B) % K
+    out = s.solve_batch(tin)
+    checked, moved = 0, 0.0
+    for k in range(K):
+        pick = np.where(tin["reserved"] == k)[0][:6]
+        op = O.default_params(N, mass=ps[k].mass, h_des=ps[k].h_des, q_p=ps[k].q_p, q_u=ps[k].q_u, q_v=ps[k].q_v, foot_width=ps[k].foot_width)
+        ref, _ = O.Oracle(op, ftsp).solve(tin[pick])
+        flat, _ = O.Oracle(op).solve(tin[pick])
+        moved = max(moved, np.abs(ref["u0"][:, 0] - flat["u0"][:, 0]).max())
+        o = out[pick]
+        ok = ((ref["status"] | o["status"]) & q.ST_ERROR_MASK) == 0
+        rel = np.abs(o["com_pos"] - ref["com_pos"]).max(1) / np.maximum(np.abs(ref["com_pos"]).max(1), 1e-3)
+        assert rel[ok].max(initial=0.0) <= TOL, (k, rel)
+        assert np.abs(o["com_vel"] - ref["com_vel"])[ok].max(initial=0.0) <= TOL
+        scale = np.maximum(np.array([9.81 * ps[k].mass, 1.0, 1.0])[None, :], np.abs(ref["u0"][ok]))
+        assert (np.abs(o["u0"] - ref["u0"])[ok] <= TOL * scale).all(), k
+        assert (o["status"][ok] == ref["status"][ok]).all()
+        checked += int(ok.sum())
+    assert checked >= 4 * K and moved > 1.0
+    s.close()
+    p = q.default_params(N=N)
+    plain, same = q.MPCSolver(ftsp, params=p), q.MPCSolver.sweep(ftsp, [p, p, p])
+    t3 = tin[:300].copy(); t3["reserved"] = np.arange(300) % 3
+    a, b = plain.solve_batch(t3), same.solve_batch(t3)
+    assert np.array_equal(a["status"], b["status"]) and np.abs(a["com_pos"] - b["com_pos"]).max() <= 1e-9 and np.abs(a["com_vel"] - b["com_vel"]).max() <= 1e-9
+    assert (np.abs(a["u0"] - b["u0"]) <= 1e-8 * np.maximum(np.abs(a["u0"]), 1.0)).all()
+    plain.close(); same.close()
+
+
 def test_sweep_with_eight_lanes_per_instance(q, sweep64, monkeypatch):
     """ISMPC_LPI=8: beyond 8 192 instances per launch a sweep handle runs eight instances per wavefront over the 8-lane copy of every
     set's tables (opt-in: measured no faster than 16 lanes when the instances of a wavefront use different sets).  Same records as the
