@@ -371,6 +371,19 @@ def lib_sha256(path=None):
     return _LIB_SHA[path]
 
 
+def lib_src_sha256(path=None):
+    """sha256 of the SOURCES the loaded library was built from (quadruped_gait_generation_ismpc_amd/build.py::source_sha256, written next to
+    the library at build time).  The library's own bytes embed the paths of its sources, so the same sources built in another directory
+    have another lib_sha256; this value is path-independent."""
+    if path is None:
+        from quadruped_gait_generation_ismpc_amd import _lib
+        path = _lib.LIB_PATH
+    try:
+        return open(path + ".src_sha256").read().strip() or None
+    except OSError:
+        return None
+
+
 def roofline(leg, kernel, kernel_ms, batch, dtype, alg_flops, alg_bytes, extra=None, note=""):
     """The contract's roofline object for one leg.  `achieved` / `frac` are a MEASUREMENT of what the kernel executes: the
     floating-point wave-instructions the SQ counted for this kernel on this batch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_{F64,F32},
@@ -390,11 +403,15 @@ def roofline(leg, kernel, kernel_ms, batch, dtype, alg_flops, alg_bytes, extra=N
     if not j or j.get("batch") != batch or j.get("kernel", "") not in kernel:
         rf["note"] += "  (no PMC summary for this leg / batch under profiles/r04: achieved, frac, traffic left null)"
         return rf
-    sha = lib_sha256()
+    sha, src = lib_sha256(), lib_src_sha256()
     rf["lib_sha256"] = sha; rf["pmc_lib_sha256"] = j.get("lib_sha256"); rf["pmc_git_head"] = j.get("git_head")
-    if sha is None or j.get("lib_sha256") != sha:
+    rf["src_sha256"] = src; rf["pmc_src_sha256"] = j.get("src_sha256")
+    same_binary = sha is not None and j.get("lib_sha256") == sha
+    same_sources = src is not None and j.get("src_sha256") == src          # the same code built in another directory (paths are embedded in the binary)
+    rf["pmc_matches_lib"] = bool(same_binary or same_sources)
+    if not (same_binary or same_sources):
         # the counters were collected from another build of the library than the one loaded now: no executed-work figure is derived from them
-        rf["note"] += "  (STALE PMC summary: its lib_sha256 is not the loaded library's; achieved, frac, traffic left null -- rerun scripts/profile_r04.sh)"
+        rf["note"] += "  (STALE PMC summary: neither its lib_sha256 nor its src_sha256 is the loaded library's; achieved, frac, traffic left null -- rerun scripts/profile_r04.sh)"
         return rf
     c, d = j.get("counters_mean_per_launch", {}), j.get("derived", {})
     per_step = float(j.get("launches_per_step", 1))
@@ -899,7 +916,7 @@ def compact_roofline(rf, full=True):
                "kernel_ms_train": _sig(rf.get("kernel_ms_train")), "algorithmic_credit": {"tflops": _sig((rf.get("algorithmic_credit") or {}).get("tflops")),
                                                                                          "bytes_per_launch": _sig((rf.get("algorithmic_credit") or {}).get("bytes_per_launch"))},
                "valu_busy_frac": _sig(ex.get("valu_busy_frac"), 3), "fp_share": _sig(ex.get("fp_share_of_valu_instructions"), 3),
-               "pmc_matches_lib": (rf.get("pmc_lib_sha256") is not None and rf.get("pmc_lib_sha256") == rf.get("lib_sha256"))}
+               "pmc_matches_lib": bool(rf.get("pmc_matches_lib"))}
     return out
 
 

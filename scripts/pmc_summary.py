@@ -26,6 +26,10 @@ try:
     res["lib_sha256"] = hashlib.sha256(open(_lib, "rb").read()).hexdigest()
 except OSError:
     res["lib_sha256"] = None
+try:
+    res["src_sha256"] = open(_lib + ".src_sha256").read().strip() or None      # the sources that library was built from (path-independent)
+except OSError:
+    res["src_sha256"] = None
 head = os.environ.get("ISMPC_GIT_HEAD")
 if not head:
     try:

@@ -15,20 +15,21 @@ def bench(tmp_path, monkeypatch):
     spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
     monkeypatch.setenv("ISMPC_PROFILES_DIR", str(tmp_path))
-    monkeypatch.setattr(b, "lib_sha256", lambda path=None: SHA)          # the library "loaded" in these tests
+    monkeypatch.setattr(b, "lib_sha256", lambda path=None: SHA)          # the library "loaded" in these tests ...
+    monkeypatch.setattr(b, "lib_src_sha256", lambda path=None: SRC)      # ... and the sources it was built from
     return b, tmp_path
 
 
-SHA = "5" * 64
+SHA, SRC = "5" * 64, "7" * 64
 
 
-def _pmc(path, leg, batch, kernel, fl64, fl32, valu, active=None, busy=None, fetch=1000.0, write=500.0, sha=SHA):
+def _pmc(path, leg, batch, kernel, fl64, fl32, valu, active=None, busy=None, fetch=1000.0, write=500.0, sha=SHA, src=SRC):
     c = {"SQ_INSTS_VALU": valu}
     if active is not None:
         c["SQ_ACTIVE_INST_VALU"] = active; c["SQ_BUSY_CYCLES"] = busy
     d = {"flops_f64_per_launch": fl64, "flops_f32_per_launch": fl32, "fp_insts_f64_per_launch": fl64 / 100.0, "fp_insts_f32_per_launch": fl32 / 100.0,
          "fp_share_of_valu_insts": 0.4, "hbm_bytes_per_launch": 2.0 * fetch * 1024 + write * 1024}
-    json.dump({"kernel": kernel, "batch": batch, "leg": leg, "launches_per_step": 1, "counters_mean_per_launch": c, "derived": d, "lib_sha256": sha, "git_head": "abc1234"},
+    json.dump({"kernel": kernel, "batch": batch, "leg": leg, "launches_per_step": 1, "counters_mean_per_launch": c, "derived": d, "lib_sha256": sha, "src_sha256": src, "git_head": "abc1234"},
               open(path / f"pmc_{leg}.json", "w"))
 
 
@@ -91,9 +92,13 @@ def test_a_counter_summary_of_another_build_is_not_used(bench):
     """pmc_*.json carries the sha256 of the library it was collected from (scripts/pmc_summary.py); bench.py derives achieved / frac /
     traffic from it only when that is the library loaded now."""
     b, tmp = bench
-    _pmc(tmp, "headline_b65536", 65536, "ismpc_tick_quad<", 8e8, 0.0, 2.2e7, sha="0" * 64)
+    _pmc(tmp, "headline_b65536", 65536, "ismpc_tick_quad<", 8e8, 0.0, 2.2e7, sha="0" * 64, src="1" * 64)
     rf = b.roofline("headline_b65536", "ismpc_tick_quad<13, 8, false>", 0.05, 65536, "f64", 4e9, 1e7)
     assert rf["achieved"] is None and rf["frac"] is None and rf["traffic"] is None and rf["executed"] is None and "STALE" in rf["note"]
+    # the same SOURCES built in another directory (the binary embeds its source paths: another lib_sha256) are the same code: accepted
+    _pmc(tmp, "headline_b65536", 65536, "ismpc_tick_quad<", 8e8, 0.0, 2.2e7, sha="0" * 64)
+    rf2 = b.roofline("headline_b65536", "ismpc_tick_quad<13, 8, false>", 0.05, 65536, "f64", 4e9, 1e7)
+    assert rf2["frac"] is not None and rf2["pmc_matches_lib"] is True and b.compact_roofline(rf2)["pmc_matches_lib"] is True
     assert rf["algorithmic_credit"]["tflops"] > 0 and rf["pmc_lib_sha256"] == "0" * 64 and rf["lib_sha256"] == SHA
     assert b.compact_roofline(rf)["pmc_matches_lib"] is False and b.compact_roofline(rf)["frac"] is None
     _pmc(tmp, "headline_b65536", 65536, "ismpc_tick_quad<", 8e8, 0.0, 2.2e7)              # same counters, collected from the loaded library
@@ -147,3 +152,23 @@ def test_the_line_stays_under_the_limit_and_keeps_the_contract(bench, tmp_path):
     full["other_configs"] = [leg("leg %d" % k) for k in range(40)]
     text = b.compact_line(full, "bench_detail.json")
     assert len(text) <= 6000 and json.loads(text)["roofline"]["frac"] is not None
+
+
+def test_source_hash_is_by_content_not_by_path(tmp_path, monkeypatch):
+    """build.py::source_sha256 -- what ties a counter summary to the code when the binary was built elsewhere -- depends on the content of the
+    sources, the public headers and the flags, not on where the tree sits; the library's staleness check uses the same value."""
+    import shutil
+    from quadruped_gait_generation_ismpc_amd import build as B
+    ref = B.source_sha256()
+    assert len(ref) == 64 and B.source_sha256("-DX") != ref
+    shutil.copytree(B.CSRC, tmp_path / "pkg" / "csrc"); shutil.copytree(os.path.join(B.ROOT, "include"), tmp_path / "include")
+    monkeypatch.setattr(B, "CSRC", str(tmp_path / "pkg" / "csrc")); monkeypatch.setattr(B, "ROOT", str(tmp_path))
+    assert B.source_sha256() == ref                                       # another directory, same content
+    with open(tmp_path / "pkg" / "csrc" / "ismpc_a_wave.hpp", "a") as f:
+        f.write("\n// touched\n")
+    assert B.source_sha256() != ref
+    lib = tmp_path / "lib.so"; lib.write_bytes(b"x")
+    (tmp_path / "lib.so.flags").write_text(""); (tmp_path / "lib.so.src_sha256").write_text(ref)
+    assert B._stale(str(lib), [], "") is True                             # built from other sources than the tree holds now
+    (tmp_path / "lib.so.src_sha256").write_text(B.source_sha256())
+    assert B._stale(str(lib), [], "") is False and B._stale(str(lib), [], "-DX") is True

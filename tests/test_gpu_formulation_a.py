@@ -599,9 +599,9 @@ def test_full_batch_properties_and_oracle_sample(FA, workload_name, precision, s
 def test_fp32_solve_against_fp64_and_oracle(FA, workload_name):
     """BASELINE configs[3] / [4] name fp32: GaitGenerator(precision="f32") solves the QPs in fp32 (right-hand sides formed in
     fp64, LIP update in fp64).  Same pushed batches as the bench, 4 096 instances: every status equal to the fp64 solve's,
-    next CoM within 1e-6 relative (the north star's tolerance; measured 7e-9), velocities within 5e-6 m/s, footsteps within
-    2e-5 m, first ZMP velocity within 2e-3 m/s (it moves the CoM by B_upd u0, |B_upd| = 3e-6 .. 9e-4); and the fp32 result
-    against the fp64 oracle (reference qpOASES where built) on a sample."""
+    next CoM within 2e-9 relative (the north star's tolerance is 1e-6), velocities within 3e-7 m/s, footsteps within 7e-8 m, first ZMP
+    velocity within 3e-4 m/s -- twice the measured maxima (u0 moves the CoM by B_upd u0, |B_upd| = 3e-6 .. 9e-4, which is why the CoM is
+    so much tighter than u0); and the fp32 result against the fp64 oracle (reference qpOASES where built) on a sample."""
     import torch
     from oracle import oracle_a as A
     from oracle import oracle as O
@@ -632,11 +632,13 @@ def test_fp32_solve_against_fp64_and_oracle(FA, workload_name):
     assert (o64["status"] == 0).all() and (o32["status"] == 0).all()
     com64 = np.stack([s64["x"], s64["y"]], 1); com32 = np.stack([s32["x"], s32["y"]], 1)
     rel = np.abs(com64 - com32).max(1) / np.maximum(np.abs(com64).max(1), 1e-3)
-    assert rel.max() <= 1e-6, rel.max()
-    assert np.abs(np.stack([s64["xd"], s64["yd"]], 1) - np.stack([s32["xd"], s32["yd"]], 1)).max() <= 5e-6
+    # tolerances = 2x the maxima measured on these 4 096 instances per workload (gpurun_out/parity_maxima.jsonl, round 4: next CoM 9.9e-10
+    # relative, velocity 1.4e-7 m/s, footstep 3.3e-8 m, u0 1.5e-4 m/s); rounds 2-3 held them at 1e-6 / 5e-6 / 2e-5 / 2e-3
+    assert rel.max() <= 2e-9, rel.max()
+    assert np.abs(np.stack([s64["xd"], s64["yd"]], 1) - np.stack([s32["xd"], s32["yd"]], 1)).max() <= 3e-7
     _record_maxima(f"fp32_vs_fp64:{workload_name}", dict(com_rel=rel.max(), vel=np.abs(np.stack([s64["xd"], s64["yd"]], 1) - np.stack([s32["xd"], s32["yd"]], 1)).max(),
                                                         f0=np.abs(o64["f0"] - o32["f0"]).max(), u0=np.abs(o64["u0"] - o32["u0"]).max(), sample=B))
-    assert np.abs(o64["f0"] - o32["f0"]).max() <= 2e-5 and np.abs(o64["u0"] - o32["u0"]).max() <= 2e-3
+    assert np.abs(o64["f0"] - o32["f0"]).max() <= 7e-8 and np.abs(o64["u0"] - o32["u0"]).max() <= 3e-4
     assert np.array_equal(s64["fc"], s32["fc"]) and np.array_equal(s64["j"], s32["j"])               # counters bit exact
     # the fp32 result against the oracle
     backend = "ref" if O.have_ref() else "gi"
@@ -654,8 +656,8 @@ def test_fp32_solve_against_fp64_and_oracle(FA, workload_name):
         for k in ("x", "y"):
             assert abs(s32[k][i] - after[k]) <= 1e-6 * max(abs(after[k]), 1e-3), (i, k)
         for k in ("xd", "yd"):
-            assert abs(s32[k][i] - after[k]) <= 5e-6, (i, k)
-        assert np.abs(o32["f0"][i] - r["f0"]).max() <= 2e-5, i
+            assert abs(s32[k][i] - after[k]) <= 3e-7, (i, k)
+        assert np.abs(o32["f0"][i] - r["f0"]).max() <= 7e-8, i
 
 
 @pytest.mark.parametrize("name", sorted(META))
@@ -714,6 +716,8 @@ def test_heavily_pushed_flags_match_reference_solver(FA, precision):
     assert np.array_equal(inf_gpu, inf_ref), np.argwhere(inf_gpu != inf_ref)[:10]
     ok = ~inf_ref
     tol_u = (TOL_U0[backend] if precision == "f64" else 2e-3)
+    _record_maxima(f"heavily_pushed:{precision}:{backend}", dict(u0=np.abs(out["u0"] - u_ref)[ok].max() / max(1.0, np.abs(u_ref[ok]).max()),
+                                                                 f0=np.abs(out["f0"] - f_ref)[ok].max(), vel=0.0, com_rel=0.0, sample=int(ok.sum())))
     assert np.abs(out["u0"] - u_ref)[ok].max() <= tol_u * max(1.0, np.abs(u_ref[ok]).max())
     assert np.abs(out["f0"] - f_ref)[ok].max() <= (1e-7 if precision == "f64" else 2e-5)
     assert ((out["active"] & 0xffff) >= w["C"]).any() or ((out["active"] >> 16) >= w["C"]).any()     # saturated horizons are in the set
