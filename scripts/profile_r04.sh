@@ -10,6 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=$R/gpurun_out/profi
 cd /tmp && export TMPDIR=/tmp
 ALL=0; [ $# -eq 0 ] && ALL=1
 ONLY_BUILD=0; [[ "$*" == "sweep_build" ]] && { ONLY_BUILD=1; set -- none; }      # `profile_r04.sh sweep_build`: only the sweep-build block at the end
+ONLY_FINAL=0; [[ "$*" == "final" ]] && { ONLY_FINAL=1; set -- none; }            # `profile_r04.sh final`: only the driver-command block (a gpurun call is at most 20 minutes: the legs go in several calls)
 LEGS=${@:-headline shard_b8192 shard_b16384 shard_b32768 config1_b1024 sweep_k64_b65536 config3_walk_C150 config3_walk_C150:f32 config4_mc_C200 config4_mc_C200:f32}
 for spec in $LEGS; do
   [[ $spec == none ]] && continue
@@ -64,8 +65,9 @@ if [ $ALL -eq 1 ] || [ $ONLY_BUILD -eq 1 ]; then
   rm -rf $OUT/tmp_sweep_build/*/*/*agent_info.csv
 fi
 # the complete line (every leg, host-path extras, cpu_baseline) and the box's VALU rates, when the whole set was regenerated
-if [ $ALL -eq 1 ]; then
+if [ $ALL -eq 1 ] || [ $ONLY_FINAL -eq 1 ]; then
   export ISMPC_PROFILES_DIR=$OUT
+  [ -d $R/profiles/r04 ] && [ $ONLY_FINAL -eq 1 ] && export ISMPC_PROFILES_DIR=$R/profiles/r04      # the summaries of the earlier calls, already copied in place
   # the EXACT driver command, once under rocprofv3 --kernel-trace --stats (its kernel_stats.csv: "dominant kernel time per step <= driver
   # ms_per_step" can be checked from the files) and once plain (the line the driver would record + bench_detail.json)
   rm -rf $OUT/tmp_driver; mkdir -p $OUT/tmp_driver
