@@ -552,7 +552,8 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
         # the product's multi-GPU path: one native group per rank (its own handle, launch stream, side stream, RCCL communicator); the
         # shard's kernel writes into the gathered buffer in place and ONE ncclAllGather completes it on every GPU (csrc/ismpc_group.hip)
         from quadruped_gait_generation_ismpc_amd import group as G
-        grp = G.Group.from_rank(q.reference_plan(params=p), p, R.local_rank, R.unique_id(), rank, world)
+        with stdout_to_stderr():
+            grp = G.Group.from_rank(q.reference_plan(params=p), p, R.local_rank, R.unique_id(), rank, world)
         assert grp.world == world and grp.shard(global_batch) == (first, B)
         grp.reserve(global_batch)
         torch.cuda.synchronize()                                         # d_in is complete before the group's own streams read it
@@ -710,6 +711,21 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
     return res
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on file descriptor 1 when a process creates its first communicator; rank 0's stdout carries the ONE
+    JSON line and nothing else, so communicators are created with fd 1 pointing at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1); os.close(self.saved)
+        return False
+
+
 def leg_group_one(R, q, N, batch, K, W, min_ms):
     """At --gpus 1: the multi-GPU entry points of the C ABI on the one GPU there is -- a group of one device (ncclCommInitAll), the
     double-buffered ismpc_group_step_device with its in-place ncclAllGather on the side stream.  Reports what RCCL itself says about the
@@ -717,7 +733,8 @@ def leg_group_one(R, q, N, batch, K, W, min_ms):
     torch = R.torch
     from quadruped_gait_generation_ismpc_amd import group as G, workload
     p = q.default_params(N=N)
-    g = G.Group(q.reference_plan(params=p), p, devices=[R.local_rank])
+    with stdout_to_stderr():
+        g = G.Group(q.reference_plan(params=p), p, devices=[R.local_rank])
     d_in = q.to_device(workload.make_batch(N, batch), R.dev)
     g.reserve(batch); torch.cuda.synchronize()
     walls = timed_regions(R, lambda k: g.step_device(batch, [d_in.data_ptr()], k & 1), K, W, min_ms, drain=g.sync)
@@ -819,10 +836,11 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
     if R.collective and R.abi and not R.rehearse:
         # the native group (include/ismpc_group.h): this rank's `batch` instances are shard `rank` of a global batch of world x batch
         from quadruped_gait_generation_ismpc_amd import group as G
-        if name == "mc_C200":
-            ga = G.GroupA.from_rank(FA.default_params(0, C=Cn, P=Pn, F=Fn), plans[0], R.local_rank, R.unique_id(), rank, world); ga.add_plan(plans[1])
-        else:
-            ga = G.GroupA.from_rank(FA.default_params(w["kind"], C=Cn, P=Pn, F=Fn), ce, R.local_rank, R.unique_id(), rank, world)
+        with stdout_to_stderr():
+            if name == "mc_C200":
+                ga = G.GroupA.from_rank(FA.default_params(0, C=Cn, P=Pn, F=Fn), plans[0], R.local_rank, R.unique_id(), rank, world); ga.add_plan(plans[1])
+            else:
+                ga = G.GroupA.from_rank(FA.default_params(w["kind"], C=Cn, P=Pn, F=Fn), ce, R.local_rank, R.unique_id(), rank, world)
         ga.set_precision(dtype == "f32")
         assert ga.world == world and ga.shard(world * batch) == (rank * batch, batch)
         ga.reserve(world * batch)

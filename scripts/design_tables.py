@@ -9,7 +9,11 @@ P = os.path.join(ROOT, "profiles", "r04")
 
 def line(path):
     try:
-        return json.loads([l for l in open(path) if l.startswith("{")][-1])
+        return json.load(open(path))                      # a whole-file object (bench_detail.json)
+    except Exception:
+        pass
+    try:
+        return json.loads([l for l in open(path) if l.startswith("{")][-1])       # the last JSON line of a captured stdout
     except Exception:
         return None
 
@@ -71,6 +75,31 @@ if h:
     if cb:
         extra.append(f"CPU beside it ({cb['cpu_model']}): reference qpOASES {cb['value']:.0f} ticks/s on one core ({cb['ms_per_unit']:.2f} ms/tick), "
                      f"{cb['all_cores']['value']:.3g} on {cb['all_cores']['cores']} cores.")
+if h:
+    cb = h.get("cpu_baseline") or {}
+    if cb.get("own"):
+        extra.append(f"The build's own CPU restatement with its dense Goldfarb–Idnani QP (SURVEY §8d (i)): {cb['own']['value']:.0f} ticks/s on one core.")
+    su = h.get("sustained")
+    if su:
+        extra.append(f"Sustained closed loop (`ismpc_rollout_device`, {su['ticks_per_call']} ticks × {su['batch']} instances per call, {su['calls']} calls back to back, "
+                     f"{su['gpu_seconds']:.1f} s of GPU time): **{su['value']:.3g} ticks/s**, {su['us_per_tick']:.1f} µs per tick of the whole batch.")
+    mg = h.get("multi_gpu")
+    if mg and mg.get("path") == "abi":
+        extra.append(f"C-ABI group of one device (`ismpc_group_step_device`, in-place `ncclAllGather` on the side stream; RCCL {mg.get('rccl_version')}, `ncclCommCount` = "
+                     f"{mg.get('rccl_world')}): {mg.get('group_step_ms', 0) * 1e3:.1f} µs per step of 65 536 instances ({mg.get('group_value', 0):.3g} ticks/s); no scaling curve measured.")
+    try:
+        ks = list(csv.DictReader(open(os.path.join(P, "driver_cmd_kernel_stats.csv"))))
+        dl = line(os.path.join(P, "driver_cmd_bench_line.json"))
+        top = [r for r in ks if h["roofline"]["kernel"] in r["Name"]]
+        if top and dl:
+            extra.append(f"The exact driver command (`python3 bench.py --gpus 1 --steps 20 --warmup 5`) under rocprofv3 (`profiles/r04/driver_cmd_kernel_stats.csv`): "
+                         f"`{h['roofline']['kernel']}` {float(top[0]['AverageNs']) / 1e3:.1f} µs average over {top[0]['Calls']} launches of the whole process (isolated launches, "
+                         f"the host-path calls and the group leg included; a launch alone is longer than its share of a train, see above), against `ms_per_step` "
+                         f"{dl['ms_per_step'] * 1e3:.1f} µs, `roofline.kernel_ms_train` {dl['roofline']['kernel_ms_train'] * 1e3:.1f} µs and `kernel_ms` {dl['roofline']['kernel_ms'] * 1e3:.1f} µs of the "
+                         f"un-profiled run of the same command (`driver_cmd_bench_line.json`: **{dl['value']:.3g} ticks/s**, `frac` {dl['roofline']['frac']:.3f}, a line of "
+                         f"{len(json.dumps(dl, separators=(',', ':')))} bytes).")
+    except (OSError, KeyError, ValueError):
+        pass
 sw = line(os.path.join(P, "sweep_k64_b65536_bench_line_unprofiled.json"))
 if sw and "sweep" in sw:
     s = sw["sweep"]
