@@ -1154,7 +1154,126 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 const R npn = isZ ? (dt * dt * (R)row + ((p_k1 >= 1 ? p_w1 * p_w1 : R(0)) + p_w2 * p_w2) * iQf) : (kr >= 2 ? R(2) : R(1));
                 R mu_p = R(0);
                 bool failed = false, fresh = true;                                // fresh: sviol still valid from the search
+#ifndef ISMPC_A_FIRST_STEP
+#define ISMPC_A_FIRST_STEP 1
+#endif
+                // ---- the FIRST row of a solve, in closed form (round 4).  At the equality-only point the working set holds the stability row
+                // alone: no active ZMP row (no neighbours, no tridiagonal part, G is its constant part), no kinematic row.  The small system then
+                // decouples -- the footstep unknowns are 0 and the stability unknown is cE = sg dt PA_row / a'a --, nothing can leave the working
+                // set (t1 = infinity), and the whole step is z_u = sg dt [i <= row] - cE a, z_f = -sg M_row / Qf with the full step length
+                // t = -violation / gamma, gamma = |n+|^2 - (dt PA_row)^2 / a'a.  These are the generic step's own numbers (same expressions) without
+                // its machinery: ~250 vector instructions instead of ~950, on every one-shot solve and every cold restart.
+                bool first_done = false;
+                if (ISMPC_A_FIRST_STEP && isZ && qz == 0 && qk == 0) {
+                    LANE_FRESH();
+                    const R dE = sg * dt * p_pa;                                   // dX of the stability column
+                    const R cE = dE * frcp((R)Dd);                                 // (Dd = a'a here: no active ZMP row)
+                    const R gamma = npn - dE * cE;
+                    if (gamma > (R)NM::gamma_rel * npn && iters < c.max_iter) {
+                        ++iters;
+                        WAVE_LDS_SYNC();                                           // L.vp is complete
+                        const R t = -sviol / gamma;
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            if (i <= C) {
+                                const R zu = -cE * ap[i - 1] + (i <= row ? sg * dt : R(0));
+                                u[k] += t * zu;
+                                if (i == row) { SET_STA_(k, sg > R(0) ? 1 : -1); mu[k] = t; }
+                                if (i < row) SET_NXT_(k, row);                     // every earlier row sees `row` as its next active row,
+                                if (i > row) SET_PRV_(k, row);                     // every later one as its previous
+                            }
+                        }
+                        if (klane) fr += t * (-sg * L.vp[lane - 1] * sq) * iQf;
+                        muE -= t * cE;
+                        const R g1 = idt2 * rinv[row];
+                        for (int e = lane; e < m * m; e += 64) { const int i = e / m, jj = e - i * m; L.G[e] += g1 * L.vp[i] * L.vp[jj]; }
+                        WAVE_LDS_SYNC();
+                        qz = 1;
+                        Dd += gap_term(0, row) + tail_term(row) - tail_term(0);
+                        first_done = true;
+                    }
+                }
+#ifndef ISMPC_A_SECOND_STEP
+#define ISMPC_A_SECOND_STEP 1
+#endif
+                // ---- the SECOND row, in closed form too (round 4; docs/models/proto_second_step.py checks these expressions against the general
+                // structured solve).  Working set = stability row + ONE ZMP row j: G = g v v' with v = V_j = [M~_j, dt PA_j], g = 1 / (j dt^2), so
+                // the small system is diag(I_F, -a'a) + g v v' and Sherman-Morrison gives its solution from a handful of wave-uniform scalars:
+                //     kappa = sg w + g (M~_j . mt)            w = row / j (row < j) or 1 (row > j): interpolation weight of the new row at j
+                //     beta = |M~_j|^2 - vE^2 / a'a ,  1 + g beta = D / a'a + g |M~_j|^2   (D = a'a - G_EE: the cancellation-free defect)
+                //     alpha = kappa - g (kappa beta + vE dX / a'a) / (1 + g beta) ;  c_f = alpha M~_j ;  cE = (dX - alpha vE) / a'a
+                //     rho_j = g (M~_j . mt - alpha beta - vE dX / a'a) + sg w
+                // Taken only when the full step is the step (t2 <= t1: row j keeps its place); a partial step goes the generic way, untouched.
+                if (ISMPC_A_SECOND_STEP && !first_done && isZ && qz == 1 && qk == 0 && iters < c.max_iter) {
+                    LANE_FRESH();
+                    const int pnr = at_row<int, RL>(pn, row);
+                    const int na = PN_PRV(pnr), nb = PN_NXT(pnr);
+                    const int jr = na > 0 ? na : nb;                               // the one active ZMP row
+                    const int sj = ((at_row<int, RL>(pn, jr) >> 18) & 3) - 1;      // +1 lower bound, -1 upper bound
+                    const R mu_j = at_row<R, RL>(mu, jr);
+                    const int b1 = L.k1s[jr - 1]; const R w1j = L.w1s[jr - 1], w2j = R(1) - w1j;
+                    const R vE = dt * pap[jr];
+                    const R g = idt2 * rinv[jr];
+                    R mm = R(0);                                                   // M_row . M_j over the footstep columns
+                    { const int a1 = p_k1;
+                      if (a1 >= 1) { if (a1 == b1) mm += p_w1 * w1j; else if (a1 == b1 + 1) mm += p_w1 * w2j; }
+                      { const int cx = a1 + 1; if (cx == b1 && b1 >= 1) mm += p_w2 * w1j; else if (cx == b1 + 1) mm += p_w2 * w2j; } }
+                    const R vmt = sg * mm * iQf;                                   // M~_j . mt
+                    const R v11 = ((b1 >= 1 ? w1j * w1j : R(0)) + w2j * w2j) * iQf;   // |M~_j|^2
+                    const R wint = (nb > 0) ? (R)row * rinv[nb] : R(1);
+                    const R dX = sg * dt * p_pa;
+                    const R iaa = frcp(aa);
+                    const R kappa = sg * wint + g * vmt;
+                    const R beta = v11 - vE * vE * iaa;
+                    const R den = (R)Dd * iaa + g * v11;                           // 1 + g beta
+                    const R xs = vE * dX * iaa;
+                    const R alpha = kappa - g * (kappa * beta + xs) * frcp(den);
+                    const R cE = (dX - alpha * vE) * iaa;
+                    const R rho = g * (vmt - alpha * beta - xs) + sg * wint;       // unsigned: the multiplier of row j moves by -t sj rho
+                    const R dj = sg * (dt * dt * (R)min(row, jr) + mm * iQf);
+                    const R gamma = npn - (dj * rho + dX * cE);
+                    const R rs = (sj > 0 ? R(1) : R(-1)) * rho;
+                    const R t1 = (rs > R(0)) ? mu_j * frcp(rs) : R(INFINITY);
+                    const R t2 = (gamma > (R)NM::gamma_rel * npn) ? -sviol / gamma : R(INFINITY);
+                    if (den > R(0.05) && t2 < R(INFINITY) && t2 <= t1) {
+                        ++iters;
+                        const R t = t2;
+                        const R vj_e = (lane < m) ? border_elem<R, F>(lane, b1, w1j, pap[jr], dt, isq) : R(0);     // V_j, one element per lane
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int i = lane * RL + k + 1;
+                            if (i <= C) {
+                                const R zu = (i <= row ? sg * dt : R(0)) - (i <= jr ? dt * rho : R(0)) - cE * ap[i - 1];
+                                u[k] += t * zu;
+                                if (i == jr) mu[k] -= t * rs;
+                                if (i == row) { SET_STA_(k, sg > R(0) ? 1 : -1); mu[k] = t; }
+                                if (i >= na && i < row) SET_NXT_(k, row);
+                                if (i > row && (nb == 0 || i <= nb)) SET_PRV_(k, row);
+                            }
+                        }
+                        if (klane) {
+                            const R mrow = border_elem<R, F>(lane - 1, p_k1, p_w1, p_pa, dt, isq), mj = border_elem<R, F>(lane - 1, b1, w1j, pap[jr], dt, isq);
+                            fr += t * (-sg * mrow * sq + sq * alpha * mj) * iQf;
+                        }
+                        muE -= t * cE;
+                        const R va = na > 0 ? vj_e : R(0), vb = nb > 0 ? vj_e : R(0);
+                        if (lane < m) { L.d1[lane] = vp - va; L.d2[lane] = vb - vp; L.d0[lane] = vb - va; }
+                        WAVE_LDS_SYNC();
+                        const R g1 = idt2 * rinv[row - na], g2 = nb > 0 ? idt2 * rinv[nb - row] : R(0), g0 = nb > 0 ? idt2 * rinv[nb - na] : R(0);
+                        for (int e = lane; e < m * m; e += 64) {
+                            const int i = e / m, jj = e - i * m;
+                            L.G[e] += g1 * L.d1[i] * L.d1[jj] + g2 * L.d2[i] * L.d2[jj] - g0 * L.d0[i] * L.d0[jj];
+                        }
+                        WAVE_LDS_SYNC();
+                        qz = 2;
+                        Dd += (nb > 0) ? gap_term(na, row) + gap_term(row, nb) - gap_term(na, nb)
+                                       : gap_term(na, row) + tail_term(row) - tail_term(na);
+                        first_done = true;
+                    }
+                }
                 // ================= steps until the row enters (Goldfarb-Idnani) =================
+                if (!first_done)
                 for (;;) {
                     LANE_FRESH();
                     if (++iters > c.max_iter) { status |= ISMPC_A_ST_ITER_LIMIT; failed = true; break; }
