@@ -503,7 +503,7 @@ def kernel_name_b(N, B, cus, sweep=False, deferring=False):
     if path == "wave" or N > 128:
         return "ismpc_tick_affine<%d>" % ((N + 63) // 64)
     lpi = _lpi(B)
-    slpi = 8 if (B > 8192 and os.environ.get("ISMPC_LPI") == "8") else 16   # sweep handles: 16 lanes per instance (ISMPC_LPI=8: 8 beyond 8 192, measured no faster)
+    slpi = 8 if (B > 8192 and os.environ.get("ISMPC_LPI") != "16") else 16  # sweep handles: 16 lanes per instance up to 8 192 instances, 8 beyond (ISMPC_LPI=16: 16 at every size)
     if one_launch(N, B, cus) and os.environ.get("ISMPC_Z_FALLBACK") != "0":
         # beyond the resident size the library goes back to two launches while instances are being deferred (launch() in csrc/ismpc_hip.hip)
         big_one = not deferring or os.environ.get("ISMPC_ONE_LAUNCH") == "3"

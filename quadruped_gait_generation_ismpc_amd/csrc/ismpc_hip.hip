@@ -2356,10 +2356,12 @@ static int create_impl(const ismpc_params* params, int K, bool sweep, const doub
         // every set's tables, built on the device (MFMA Newton-Schulz inverse of the K vertical Hessians, csrc/ismpc_sweep.hip), and one
         // DevConst record per set: the handle's, with the set's scalars and table pointers in place of set 0's host-built ones
         std::string serr;
-        // 8 lanes per instance beyond LPI16_BATCH, as plain handles take them, is opt-in here (ISMPC_LPI=8): with eight instances of a
-        // wavefront reading eight sets' tables it measured level to 2 % slower on the 64-set batch (9.25-9.28 against 9.27-9.43e8 ticks/s)
+        // 8 lanes per instance beyond LPI16_BATCH, as plain handles take them (ISMPC_LPI=16 keeps 16 at every size).  With eight instances
+        // of a wavefront reading eight sets' tables it measured level to 2 % slower on the 64-set batch (round 3: 9.25-9.28 against
+        // 9.27-9.43e8 ticks/s); with the batch sorted by set (ismpc_sweep_bind: one set per wavefront) it is 5 % faster (round 4: 9.65-9.71
+        // against 9.17-9.26e8), so it is the default now
         const char* lp8 = std::getenv("ISMPC_LPI");
-        const bool lanes8 = lp8 && std::atoi(lp8) == 8;
+        const bool lanes8 = !(lp8 && std::atoi(lp8) == 16);
         rc = ismpc::sweep_build(params, K, h->t, c.midx, c.midy, c.midz, c.e_lo, c.ne, 16, quad_R(t.p.N, 16), lanes8 ? 8 : 0, quad_R(t.p.N, 8), h->own_stream, h->sw, h->dev_allocs, serr);
         if (rc != ISMPC_OK) { ismpc_destroy(h); return fail(rc, serr); }
         std::vector<DevConst> cs((size_t)K, h->c);

@@ -69,8 +69,9 @@ def test_kernel_names_and_credits_follow_the_launch_rules(bench, monkeypatch):
         monkeypatch.delenv(k, raising=False)
     assert b.kernel_name_b(100, 65536, 256) == "ismpc_tick_quad_one<13, 8, 2, false>"     # > 8 wavefronts per CU: one launch at the tick's own residency; 8 lanes per instance beyond 8 192
     assert b.kernel_name_b(100, 16384, 256) == "ismpc_tick_quad_inline<13, 8, 2>"         # eight instances per wavefront: 16 384 are resident at once
-    assert b.kernel_name_b(100, 65536, 256, sweep=True) == "ismpc_tick_quad_one<7, 16, 2, true>"
-    assert b.kernel_name_b(100, 65536, 256, sweep=True, deferring=True) == "ismpc_tick_quad<7, 16, true>"   # ... two while instances are deferred
+    assert b.kernel_name_b(100, 65536, 256, sweep=True) == "ismpc_tick_quad_one<13, 8, 2, true>"          # sweep handles: 8 lanes beyond 8 192 too (round 4)
+    assert b.kernel_name_b(100, 65536, 256, sweep=True, deferring=True) == "ismpc_tick_quad<13, 8, true>"   # ... two launches while instances are deferred
+    assert b.kernel_name_b(100, 8192, 256, sweep=True, deferring=True) == "ismpc_tick_quad<7, 16, true>"
     assert b.kernel_name_b(100, 65536, 256, deferring=True) == "ismpc_tick_quad<13, 8, false>"
     assert b.kernel_name_b(100, 8192, 256, deferring=True) == "ismpc_tick_quad_inline<7, 16, 2>"
     monkeypatch.setenv("ISMPC_ONE_LAUNCH", "0")
