@@ -1097,6 +1097,9 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             int gi_adds = 0;
             bool gi_leave = false;                                // feasible, or failed: nothing more to do
             for (;;) {
+                // the exact steps of phase 0 are spent: the block passes take over -- and evaluate every row themselves, so no search for a row
+                // that would not be added (round 4: that search was ~170 vector instructions of every one-shot solve, for a `break`)
+                if (phase == 0 && gi_adds >= gi_limit) break;
                 // ================= most violated inactive row =================
                 LANE_FRESH();
                 R cand = R(0), craw = R(0); int code = 0;
