@@ -25,7 +25,17 @@ struct DevA {
     const double *clx0, *cly0, *clx1, *cly1;   // centreline: initial / rebuilt structure, 0-based (cl(k+1))
     double* scratch;                   // per-workgroup S^-1 : ldq x ldq doubles each
     const double *plan_x[4], *plan_y[4]; int nplans; double grav;   // base plans selectable per instance (ismpc_a_inst.plan)
+    // anticipative tail of the handle's own gait parameters as a function of the tick index alone (quad_walk_no_plots.m:227-231):
+    // T[j] = sum_{i=C+1..P} wtail_i cl(j+i) + wP cl(P), per centreline table; the tail of a tick is T[j] + (offset - current footstep) sumw
+    const double *tlx0, *tly0, *tlx1, *tly1;
 };
+
+// Per-instance gait parameters (ismpc_a_inst): what depends on the instance alone and costs transcendental functions, divisions or
+// reductions -- eta, lambda = exp(-eta dt) and its powers, the coefficients of the stability row a_i = k1c lambda^i - k2c
+// (quad_walk_no_plots.m:233-238) and of its prefix sums in closed form
+//     sum_{k<i} a_k   = A1 (1 - lambda^i) - i k2c,      sum_{k<i} a_k^2 = A2 (1 - lambda^2i) - B2 (1 - lambda^i) + i k2c^2
+// -- computed by one thread per instance in the tick prologue instead of by all 64 lanes of each of its two QPs (round 4).
+struct PiPre { double eta, lam, lamC, lamP, k1c, k2c, A1, A2, B2, aa; };
 
 // One launch of the wavefront-per-QP kernel.  precision: 0 = the QP is solved in fp64, 1 = in fp32 (state, right-hand sides
 // and the LIP update stay fp64).
@@ -41,6 +51,7 @@ struct WaveLaunch {
     int* defer_list; int* defer_count;            // ... whose fp32 block solve failed its check (NULL: such a QP starts cold instead)
     int grid_cap;                                 // > 0: at most this many workgroups (the re-solve launch)
     hipStream_t stream;
+    const PiPre* pre = nullptr;                   // per-instance launches (inst != NULL): the prologue's record of every instance
 };
 
 // Implemented in ismpc_a_wave_rl{2,3,4}.hip.  Return 0, -1 (no instantiation for this F) or -2 (HIP error, *err set).

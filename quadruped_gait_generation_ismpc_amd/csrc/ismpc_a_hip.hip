@@ -635,11 +635,27 @@ __global__ void ismpc_a_bucket_by_F(const ismpc_a_inst* __restrict__ inst, int b
 // Everything a tick needs before its solver launch, in one launch instead of a copy, a clear and a memset: the snapshot of the
 // state the two QPs of an instance read (the solver updates `state` in place), cleared flags of the output records, zeroed
 // work counters.  96-byte state records move as six 16-byte words per thread.
-__global__ void ismpc_a_tick_prologue(const ismpc_a_state* __restrict__ state, ismpc_a_state* __restrict__ prev, ismpc_a_out* out, int batch, int* counters)
+// With per-instance gait parameters also the PiPre record of every instance (ismpc_a_dev.hpp).
+__global__ void ismpc_a_tick_prologue(const ismpc_a_state* __restrict__ state, ismpc_a_state* __restrict__ prev, ismpc_a_out* out, int batch, int* counters,
+                                      const ismpc_a_inst* __restrict__ inst, ismpc_a::PiPre* __restrict__ pre, double grav, double dt, int C, int P)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 4 && counters) counters[i] = 0;
     if (i >= batch) return;
+    if (inst && pre) {
+        const double height = inst[i].height;
+        const double eta = (height > 0) ? sqrt(grav / height) : 1.0;      // (a record the solver rejects: any finite values)
+        const double lam = exp(-eta * dt);
+        auto ipw = [](double b, int n) { double r = 1.0; while (n > 0) { if (n & 1) r *= b; b *= b; n >>= 1; } return r; };
+        const double lamC = ipw(lam, C), lamP = ipw(lam, P);
+        const double r1 = 1.0 / (1.0 - lam);
+        const double k1c = (1 / eta) * (1 - lam) / (1 - lamC), k2c = dt * 1.0 * lamC;
+        ismpc_a::PiPre q;
+        q.eta = eta; q.lam = lam; q.lamC = lamC; q.lamP = lamP; q.k1c = k1c; q.k2c = k2c;
+        q.A1 = k1c * r1; q.A2 = k1c * k1c / ((1.0 - lam) * (1.0 + lam)); q.B2 = 2.0 * k1c * k2c * r1;
+        q.aa = (q.A2 * ((1.0 - lamC) * (1.0 + lamC)) - q.B2 * (1.0 - lamC)) + (double)C * (k2c * k2c);     // = the kernel's sum_{k<C} a_k^2
+        pre[i] = q;
+    }
     static_assert(sizeof(ismpc_a_state) % 16 == 0, "state record: whole 16-byte words");
     const double2* src = reinterpret_cast<const double2*>(state + i);
     double2* dst = reinterpret_cast<double2*>(prev + i);
@@ -700,6 +716,7 @@ struct ismpc_a_handle {
     FeetParamsSet feet_set{}; int feet_plans = 0;        // ... and per base plan (ismpc_a_feet_init_inst_device)
     bool use_wave = true; int wave_blocks = 0;           // structured wavefront-per-QP kernel (default) vs workgroup-per-QP
     int cus = 0, wave_occ[16] = {0};                     // resident workgroups per CU of the wave kernels ([F - 3][precision x per-instance])
+    ismpc_a::PiPre* pre = nullptr; int pre_cap = 0;       // per-instance launches: the prologue's record per instance
     int* order = nullptr; int order_cap = 0;             // per-instance launches: instance lists by footstep count (4 x cap) + 4 counters
     bool bucket_by_F = false;                            // ISMPC_A_BUCKET=1: one launch per footstep count instead of one launch of the widest kernel
                                                          // (measured slower: 6.2 vs 4.0 ms at 16 384 instances -- four tails of 100-iteration QPs instead of one)
@@ -906,6 +923,21 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     if (!rc) rc = upload_a(h, cly0, &c.cly0);
     if (!rc) rc = upload_a(h, clx1, &c.clx1);
     if (!rc) rc = upload_a(h, cly1, &c.cly1);
+    // the tail sums of the wave kernel, one per tick index and centreline table (long double: they replace a 64-lane fp64 reduction)
+    auto tail_table = [&](const std::vector<double>& cl, const double** dst) -> int {
+        const int nt = c.ncl - p->P + 1;
+        std::vector<double> T(std::max(nt, 1), 0.0);
+        for (int j = 0; j < nt; ++j) {
+            long double s = 0.0L;
+            for (int i = p->C + 1; i <= p->P; ++i) s += (long double)wt[i - (p->C + 1)] * (long double)cl[j + i - 1];
+            T[j] = (double)(s + (long double)c.wP * (long double)cl[p->P - 1]);
+        }
+        return upload_a(h, T, dst);
+    };
+    if (!rc) rc = tail_table(clx0, &c.tlx0);
+    if (!rc) rc = tail_table(cly0, &c.tly0);
+    if (!rc) rc = tail_table(clx1, &c.tlx1);
+    if (!rc) rc = tail_table(cly1, &c.tly1);
     if (!rc) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) rc = fail_a(-2, "hipGetDeviceProperties failed");
@@ -942,6 +974,7 @@ void ismpc_a_destroy(ismpc_a_handle* h)
     if (h->hist) (void)hipFree(h->hist);
     if (h->defer_list) (void)hipFree(h->defer_list);
     if (h->order) (void)hipFree(h->order);
+    if (h->pre) (void)hipFree(h->pre);
     if (h->feet_base) (void)hipFree(h->feet_base);
     delete h;
 }
@@ -987,6 +1020,12 @@ int ismpc_a_reserve(ismpc_a_handle* h, int max_batch)
         h->order = nullptr; h->order_cap = 0;
         HIP_TRY_A(hipMalloc((void**)&h->order, sizeof(int) * (4 * (size_t)max_batch + 4)));
         h->order_cap = max_batch;
+    }
+    if (max_batch > h->pre_cap) {
+        if (h->pre) HIP_TRY_A(hipFree(h->pre));
+        h->pre = nullptr; h->pre_cap = 0;
+        HIP_TRY_A(hipMalloc((void**)&h->pre, sizeof(ismpc_a::PiPre) * (size_t)max_batch));
+        h->pre_cap = max_batch;
     }
     if (max_batch > h->defer_cap) {
         if (h->defer_list) HIP_TRY_A(hipFree(h->defer_list));
@@ -1042,8 +1081,14 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
         HIP_TRY_A(hipMallocAsync((void**)&h->prev, sizeof(ismpc_a_state) * (size_t)batch, s));
         h->prev_cap = batch;
     }
+    if (inst_dev && batch > h->pre_cap) {
+        HIP_TRY_A(grow_sync(h, s)); if (h->pre) HIP_TRY_A(hipFreeAsync(h->pre, s));
+        h->pre = nullptr; h->pre_cap = 0;
+        HIP_TRY_A(hipMallocAsync((void**)&h->pre, sizeof(ismpc_a::PiPre) * (size_t)batch, s));
+        h->pre_cap = batch;
+    }
     hipLaunchKernelGGL(ismpc_a_tick_prologue, dim3((batch + 255) / 256), dim3(256), 0, s, (const ismpc_a_state*)state_dev, h->prev, out_dev, batch,
-                       (h->use_wave || inst_dev) ? h->work_counter : nullptr);
+                       (h->use_wave || inst_dev) ? h->work_counter : nullptr, inst_dev, inst_dev ? h->pre : nullptr, h->c.grav, h->c.dt, h->c.C, h->c.P);
     if (h->use_wave || inst_dev) {
         // structured solver, one wavefront per QP, 4 per workgroup; persistent grid (ismpc_a_wave.hpp)
         const int rl = (h->c.C + 63) / 64;
@@ -1052,7 +1097,7 @@ static int tick_launch(ismpc_a_handle* h, int batch, ismpc_a_state* state_dev, c
                                h->precision, h->cus, h->wave_occ, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, 0, s};
         // QPs per work-counter atomic (scripts/claim_sweep.sh): one device-wide atomic per QP costs 10-50 % when QPs are short (two rows
         // per lane, the fp32 solve at three, closed-loop ticks); pairs coarsen the balance too much when they are long
-        WL.static_q = h->static_q;
+        WL.static_q = h->static_q; WL.pre = inst_dev ? h->pre : nullptr;
         WL.claim_chunk = h->claim_chunk > 0 ? h->claim_chunk : ((rl <= 2 || (h->precision == 1 && rl == 3) || hist_load) ? 2 : 1);
         hipError_t werr = hipSuccess;
         int wrc = -1;

@@ -252,6 +252,22 @@ __device__ __forceinline__ double ipow(double b, int n)
     return r;
 }
 
+// lam^n for a per-lane n < 64 (six bits); *b64 = lam^64, what the squarings end on
+__device__ __forceinline__ double ipow6(double b, int n, double* b64)
+{
+    double r = 1.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { if (n & 1) r *= b; b *= b; n >>= 1; }
+    if (b64) *b64 = b;
+    return r;
+}
+// a wave-uniform value pinned to scalar registers (kept across QPs: a spilled scalar register costs a v_readlane, not scratch)
+__device__ __forceinline__ double uni(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
 // element `e` (this lane's) of the border row V = [M~ (F), dt PA, Bk (F)] of a ZMP row with mapping (k1, w1, 1-w1), PA = pa
 template <typename R, int F> __device__ __forceinline__ R border_elem(int e, int k1, R w1, R pa, R dt, R isq)
 {
@@ -285,6 +301,9 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 // against 1.95e7 at 2: 14 spilled registers now, 160 before); fp64 3 for two rows per lane (walk C=100: 5.2e7 against 4.3e7 at 2,
 // 8 spilled registers) and for three (walk C=150: 3.44e7 against 3.0e7 at 2, trot C=160 3.0e7 against 2.55e7, with 50 spilled
 // registers); 2 for four rows per lane and for per-instance parameters (LDS).
+#ifndef ISMPC_A_PAIR_SETUP       // 0: every QP builds its instance's set-up itself (A/B knob)
+#define ISMPC_A_PAIR_SETUP 1
+#endif
 #ifndef ISMPC_A_OCC_F32_RL2      // tuning knobs (scripts/occ_sweep.sh builds variants)
 #define ISMPC_A_OCC_F32_RL2 3
 #endif
@@ -319,7 +338,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                        const ismpc_a_inst* __restrict__ ipar, const double* __restrict__ push, ismpc_a_out* __restrict__ out, int batch,
                        int* __restrict__ work_counter, unsigned long long* __restrict__ hist, int hist_load,
                        const int* __restrict__ order, const int* __restrict__ count_ptr, const int claim_chunk_, const int static_q,
-                       const int order_is_qp, int* __restrict__ defer_list, int* __restrict__ defer_count)
+                       const int order_is_qp, int* __restrict__ defer_list, int* __restrict__ defer_count, const PiPre* __restrict__ pre)
 {
     using NM = Num<R>;
     const DevA& c = *cp;                                   // handle constants, read from memory where they are used (by value they would
@@ -405,6 +424,10 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     int st_cur = gwave * share;
     const int st_end = st_cur + share, dyn_base = nwaves * share;
     PH_DECL;
+    // The two QPs of an instance (x, y) are neighbours in the hand-out, and what depends on the instance alone is built once: the row
+    // mapping (L.k1s / L.w1s) and, with per-instance gait parameters, eta, lambda and its powers, the stability row and its prefix sums
+    // (a_pi ... pa2d_pi).  All of it is written in the set-up only, so the second QP finds it in LDS (round 4).
+    int last_inst = -1, keep_ovf = 0;
     for (;;) {
         LANE_FRESH();
         PH(0);                                             // 0: between QPs
@@ -422,6 +445,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         const int qpi = order_is_qp ? order[work] : work;
         const int inst = (order && !order_is_qp) ? order[qpi >> 1] : (qpi >> 1), axis = qpi & 1;
         const int qp = 2 * inst + axis;                    // slot of this QP in the working-set history
+        const bool same = ISMPC_A_PAIR_SETUP != 0 && inst == last_inst;   // the other axis of the instance this wavefront has just set up
         const ismpc_a_state st = state_in[inst];
         const double pos = axis == 0 ? st.x : st.y;
         const double vel = (axis == 0 ? st.xd : st.yd) + (push ? push[inst * 2 + axis] : 0.0);
@@ -438,9 +462,10 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             step_ = ip.step; ds_ = ip.ds; Fi = ip.F; plan = ip.plan; Qf_d = ip.Qf;
             if (step_ < 2 || ds_ < 2 || ds_ >= step_ || Fi < 1 || Fi > F || plan < 0 || plan >= c.nplans || !(ip.height > 0) || !(Qf_d > 0)) {
                 status |= ISMPC_A_ST_BAD_INDEX; step_ = 2; ds_ = 1; Fi = 1; plan = 0; Qf_d = 1.0; eta = 1.0;
-            } else eta = sqrt(c.grav / ip.height);
+            } else eta = pre[inst].eta;
         }
-        const double lam_pi = PI ? exp(-eta * c.dt) : 0.0;   // per-instance eta: lambda = exp(-eta dt), the one transcendental of the QP
+        // per-instance eta: lambda = exp(-eta dt) and its powers come from the tick prologue (PiPre), one thread per instance
+        const double lam_pi = PI ? pre[inst].lam : 0.0, lamC_pi = PI ? pre[inst].lamC : 0.0, lamP_pi = PI ? pre[inst].lamP : 0.0;
         const R sq = (R)sqrt(Qf_d), isq = (R)(1.0 / sqrt(Qf_d)), iQf = (R)(1.0 / Qf_d);
         const float rstep = 1.0f / (float)step_;
         const double inv_dsm1 = PI ? 1.0 / (double)(ds_ - 1) : 0.0, inv_ds = 1.0 / (double)ds_;
@@ -452,42 +477,28 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             status |= ISMPC_A_ST_BAD_INDEX;
         // the band of EVERY row, relative to the current footstep (the mapping rows sum to one): -(zmp - cur) -+ w/2
         const R zlo = (R)(-(zmp - cur) - c.w / 2), zhi = (R)(-(zmp - cur) + c.w / 2);
-        R aa = (R)aa_d;
-        if (PI) {
-            // stability row a_i (quad_walk_no_plots.m:233-238), its prefix sums and a'a for this instance's eta
+        R aa = PI ? (R)pre[inst].aa : (R)aa_d;
+        if (PI && !same) {
+            // stability row a_i = k1c lambda^i - k2c (quad_walk_no_plots.m:233-238) and its prefix sums for this instance's eta: every
+            // row from lambda^i alone (closed forms, PiPre) -- no scan, no reduction, no division
             R* aw = a_pi[PI ? wv : 0]; R* paw = pa_pi[PI ? wv : 0];
-            const double lam = lam_pi;
-            const double lamC = ipow(lam, C);
-            const double k1c = (1 / eta) * (1 - lam) / (1 - lamC), k2c = c.dt * 1.0 * lamC;
             double* padw = pad_pi[PI ? wv : 0]; double* pa2dw = pa2d_pi[PI ? wv : 0];
-            // a_i = k1c lambda^i - k2c: one power per lane (its first row), then powers of lambda.  Two sweeps over the lane's rows --
-            // totals for the scan first, the running sums second -- so that no per-row fp64 array lives across the scans
-            double loc = 0.0, sqs = 0.0;
-            const double lp0 = ipow(lam, lane * RL);
-            {
-                double lp = lp0;
+            const double lam = lam_pi;
+            const double k1c = pre[inst].k1c, k2c = pre[inst].k2c, A1 = pre[inst].A1, A2 = pre[inst].A2, B2 = pre[inst].B2, k2c2 = k2c * k2c;
+            double lamR = lam;
 #pragma unroll
-                for (int k = 0; k < RL; ++k) {
-                    const double avk = (lane * RL + k < C) ? k1c * lp - k2c : 0.0;
-                    lp *= lam;
-                    loc += avk; sqs += avk * avk;
-                }
-            }
-            double run = wave_scan_up(loc) - loc, run2 = wave_scan_up(sqs) - sqs;
-            {
-                double lp = lp0;
-                asm volatile("" : "+v"(lp));                              // (opaque: the second sweep is not folded back into per-row arrays of the first)
+            for (int k = 1; k < RL; ++k) lamR *= lam;
+            double lp = ipow6(lamR, lane, nullptr);                       // lambda^(lane RL)
 #pragma unroll
-                for (int k = 0; k < RL; ++k) {
-                    const int i0 = lane * RL + k;
-                    const double avk = (i0 < C) ? k1c * lp - k2c : 0.0;
-                    lp *= lam;
-                    run += avk; run2 += avk * avk;
-                    if (i0 < C) { aw[i0] = (R)avk; paw[i0 + 1] = (R)run; padw[i0 + 1] = run; pa2dw[i0 + 1] = run2; }
-                }
+            for (int k = 0; k < RL; ++k) {
+                const int i0 = lane * RL + k;
+                const double avk = k1c * lp - k2c;
+                lp *= lam;                                                // lambda^(i0 + 1)
+                const double om = 1.0 - lp, n1 = (double)(i0 + 1);
+                const double run = A1 * om - n1 * k2c, run2 = (A2 * (om * (1.0 + lp)) - B2 * om) + n1 * k2c2;
+                if (i0 < C) { aw[i0] = (R)avk; paw[i0 + 1] = (R)run; padw[i0 + 1] = run; pa2dw[i0 + 1] = run2; }
             }
             if (lane == 0) { paw[0] = R(0); padw[0] = 0.0; pa2dw[0] = 0.0; }
-            aa = (R)wave_sum(sqs);
             WAVE_LDS_SYNC();
         }
 
@@ -512,6 +523,14 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
 #define PN_PRV(v_) ((v_) & 0x1ff)
 #define PN_NXT(v_) (((v_) >> 9) & 0x1ff)
         bool ovf = false;
+        if (same) {
+#pragma unroll
+            for (int k = 0; k < RL; ++k) {
+                const int i = lane * RL + k + 1;
+                u[k] = R(0); mu[k] = R(0);
+                pn[k] = (i <= C) ? (((int)L.k1s[i - 1] << 20) | (1 << 18)) : (1 << 18);
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < RL; ++k) {
             const int i = lane * RL + k + 1;
@@ -528,26 +547,29 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 L.k1s[i - 1] = (unsigned char)pf; L.w1s[i - 1] = w1k;
             } else if (i <= WG) L.w1s[i - 1] = R(1);
         }
-        if (__builtin_amdgcn_ballot_w64(ovf) != 0) status |= ISMPC_A_ST_OVERFLOW;
+        if (!same) keep_ovf = __builtin_amdgcn_ballot_w64(ovf) != 0;
+        if (keep_ovf) status |= ISMPC_A_ST_OVERFLOW;
         // anticipative tail (quad_walk_no_plots.m:227-231)
-        double tl = 0.0;
+        double tail = 0.0;
         if (!(status & ISMPC_A_ST_BAD_INDEX)) {
             if (PI) {
                 const double lam = lam_pi;
-                const double om = 1 - lam, l64 = ipow(lam, 64);
-                double wi = ipow(lam, C + 1 + lane) * om;
+                double l64;
+                double wi = (lamC_pi * lam) * ipow6(lam, lane, &l64) * (1 - lam);      // lambda^(C + 1 + lane) (1 - lambda)
+                double tl = 0.0;
 #pragma nounroll
                 for (int i = C + 1 + lane; i <= P; i += 64) {
                     tl += wi * ((cl_closed(fs, step_, rstep, ds_, inv_dsm1, st.rebuilt != 0, j + i - 1) + cloff) - cur);
                     wi *= l64;
                 }
-            } else
-                for (int i = C + 1 + lane; i <= P; i += 64) tl += c.wtail[i - (C + 1)] * ((cl[j + i - 1] + cloff) - cur);
+                tail = wave_sum(tl) + lamP_pi * ((cl_closed(fs, step_, rstep, ds_, inv_dsm1, st.rebuilt != 0, P - 1) + cloff) - cur);
+            } else {
+                // the handle's own parameters: the sum over the samples depends on the tick index alone (DevA::tlx0 ...: built by the host)
+                const double* tt = st.rebuilt ? (axis == 0 ? c.tlx1 : c.tly1) : (axis == 0 ? c.tlx0 : c.tly0);
+                tail = tt[j] + (cloff - cur) * c.sumw;
+            }
         }
-        double tail = wave_sum(tl);
-        if (!(status & ISMPC_A_ST_BAD_INDEX))
-            tail += PI ? ipow(lam_pi, P) * ((cl_closed(fs, step_, rstep, ds_, inv_dsm1, st.rebuilt != 0, P - 1) + cloff) - cur)
-                       : c.wP * ((cl[P - 1] + cloff) - cur);
+        last_inst = (status & ISMPC_A_ST_BAD_INDEX) ? -1 : inst;
         const R beq = (R)(pos + vel / eta - zmp - tail);
         // ---- kinematic row r and footstep f_r (relative to the current one) live in lane r (1..F); Khat_r = sqrt(Qf) (f_r - f_{r-1})
         R fr = R(0), klo = R(-INFINITY), khi = R(INFINITY), muK = R(0);
@@ -1587,14 +1609,16 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             if (push) { const double* pp = push + inst * 2 + axis; asm volatile("" : "+v"(pp)); v0 += *pp; }
             const int j2 = sp->j, fc2 = sp->fc;
             int step2 = c.step; double eta2 = c.eta;
+            const PiPre* ppre = nullptr;
             if (PI) {
                 const ismpc_a_inst* ipp = ipar + inst; asm volatile("" : "+v"(ipp));
-                if (!(status & ISMPC_A_ST_BAD_INDEX)) { step2 = ipp->step; eta2 = sqrt(c.grav / ipp->height); }
+                ppre = pre + inst; asm volatile("" : "+v"(ppre));
+                if (!(status & ISMPC_A_ST_BAD_INDEX)) { step2 = ipp->step; eta2 = ppre->eta; }
             }
             const double f0 = cur2 + df0;
             double np_, nv_, nz_;
             if (PI) {                                                            // A_upd, B_upd for this instance's eta (:67-71)
-                const double e_ = lam_pi, ie_ = 1.0 / e_;
+                const double e_ = ppre->lam, ie_ = 1.0 / e_;
                 const double ch = 0.5 * (ie_ + e_), sh = 0.5 * (ie_ - e_);          // cosh, sinh of eta dt
                 np_ = (ch * p0 + (sh / eta2) * v0 + (1 - ch) * z0) + (c.dt - sh / eta2) * u0;
                 nv_ = ((eta2 * sh) * p0 + ch * v0 + (-eta2 * sh) * z0) + (1 - ch) * u0;
@@ -1653,7 +1677,7 @@ inline int launch_one(const WaveLaunch& L, hipError_t* err)
     int grid = std::min((2 * L.batch + 3) / 4, L.cus * occ);
     if (L.grid_cap > 0) grid = std::min(grid, L.grid_cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), 0, L.stream, L.c_dev, L.prev, L.state, L.inst, L.push, L.out, L.batch, L.work_counter, L.hist, L.hist_load,
-                       L.order, L.count_ptr, L.claim_chunk, L.static_q, L.order_is_qp, L.defer_list, L.defer_count);
+                       L.order, L.count_ptr, L.claim_chunk, L.static_q, L.order_is_qp, L.defer_list, L.defer_count, L.pre);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = e; return -2; }
     return 0;
