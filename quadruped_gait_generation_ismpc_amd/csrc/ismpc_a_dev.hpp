@@ -28,6 +28,8 @@ struct DevA {
     // anticipative tail of the handle's own gait parameters as a function of the tick index alone (quad_walk_no_plots.m:227-231):
     // T[j] = sum_{i=C+1..P} wtail_i cl(j+i) + wP cl(P), per centreline table; the tail of a tick is T[j] + (offset - current footstep) sumw
     const double *tlx0, *tly0, *tlx1, *tly1;
+    // reciprocals and roots of the handle's own parameters the wave kernel would otherwise form once per QP on all 64 lanes
+    double sqQf, isqQf, iQf, ieta, inv_ds; float rstep;
 };
 
 // Per-instance gait parameters (ismpc_a_inst): what depends on the instance alone and costs transcendental functions, divisions or
@@ -35,7 +37,12 @@ struct DevA {
 // (quad_walk_no_plots.m:233-238) and of its prefix sums in closed form
 //     sum_{k<i} a_k   = A1 (1 - lambda^i) - i k2c,      sum_{k<i} a_k^2 = A2 (1 - lambda^2i) - B2 (1 - lambda^i) + i k2c^2
 // -- computed by one thread per instance in the tick prologue instead of by all 64 lanes of each of its two QPs (round 4).
-struct PiPre { double eta, lam, lamC, lamP, k1c, k2c, A1, A2, B2, aa; };
+struct PiPre {
+    double eta, lam, lamC, lamP, k1c, k2c, A1, A2, B2, aa;
+    double sqQf, isqQf, iQf, ieta, inv_ds, inv_dsm1;     // sqrt(Qf), 1 / sqrt(Qf), 1 / Qf, 1 / eta, 1 / ds, 1 / (ds - 1)
+    double ch, sh, sh_eta;                               // cosh(eta dt), sinh(eta dt), sinh(eta dt) / eta: the LIP update (:67-71)
+    float rstep; int pad_;                               // 1 / step
+};
 
 // One launch of the wavefront-per-QP kernel.  precision: 0 = the QP is solved in fp64, 1 = in fp32 (state, right-hand sides
 // and the LIP update stay fp64).

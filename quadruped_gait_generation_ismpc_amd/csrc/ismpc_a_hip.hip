@@ -654,6 +654,12 @@ __global__ void ismpc_a_tick_prologue(const ismpc_a_state* __restrict__ state, i
         q.eta = eta; q.lam = lam; q.lamC = lamC; q.lamP = lamP; q.k1c = k1c; q.k2c = k2c;
         q.A1 = k1c * r1; q.A2 = k1c * k1c / ((1.0 - lam) * (1.0 + lam)); q.B2 = 2.0 * k1c * k2c * r1;
         q.aa = (q.A2 * ((1.0 - lamC) * (1.0 + lamC)) - q.B2 * (1.0 - lamC)) + (double)C * (k2c * k2c);     // = the kernel's sum_{k<C} a_k^2
+        const double Qf = (inst[i].Qf > 0) ? inst[i].Qf : 1.0;
+        const int step = inst[i].step >= 2 ? inst[i].step : 2, ds = inst[i].ds >= 2 ? inst[i].ds : 2;
+        q.sqQf = sqrt(Qf); q.isqQf = 1.0 / sqrt(Qf); q.iQf = 1.0 / Qf; q.ieta = 1.0 / eta;
+        q.inv_ds = 1.0 / (double)ds; q.inv_dsm1 = 1.0 / (double)(ds - 1); q.rstep = 1.0f / (float)step; q.pad_ = 0;
+        const double ie = 1.0 / lam;
+        q.ch = 0.5 * (ie + lam); q.sh = 0.5 * (ie - lam); q.sh_eta = q.sh / eta;
         pre[i] = q;
     }
     static_assert(sizeof(ismpc_a_state) % 16 == 0, "state record: whole 16-byte words");
@@ -906,6 +912,8 @@ int ismpc_a_create(const ismpc_a_params* p, const double* center, int device, is
     double sumw = 0.0;
     for (int i = p->C + 1; i <= p->P; ++i) { wt[i - (p->C + 1)] = std::exp(-eta * dt * i) * (1 - std::exp(-eta * dt)); sumw += wt[i - (p->C + 1)]; }
     c.wP = std::exp(-eta * dt * p->P); c.sumw = sumw + c.wP; c.aa = aa;
+    c.sqQf = std::sqrt(c.Qf); c.isqQf = 1.0 / std::sqrt(c.Qf); c.iQf = 1.0 / c.Qf; c.ieta = 1.0 / eta;
+    c.inv_ds = 1.0 / (double)p->ds; c.rstep = 1.0f / (float)p->step;
     h->fsx.resize(p->n_gait); h->fsy.resize(p->n_gait);
     for (int i = 0; i < p->n_gait; ++i) { h->fsx[i] = center[i * 2]; h->fsy[i] = center[i * 2 + 1]; }
     std::vector<double> clx0, cly0, clx1, cly1;

@@ -466,9 +466,13 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
         }
         // per-instance eta: lambda = exp(-eta dt) and its powers come from the tick prologue (PiPre), one thread per instance
         const double lam_pi = PI ? pre[inst].lam : 0.0, lamC_pi = PI ? pre[inst].lamC : 0.0, lamP_pi = PI ? pre[inst].lamP : 0.0;
-        const R sq = (R)sqrt(Qf_d), isq = (R)(1.0 / sqrt(Qf_d)), iQf = (R)(1.0 / Qf_d);
-        const float rstep = 1.0f / (float)step_;
-        const double inv_dsm1 = PI ? 1.0 / (double)(ds_ - 1) : 0.0, inv_ds = 1.0 / (double)ds_;
+        // roots and reciprocals of the gait parameters: formed once per handle (DevA) or per instance (PiPre), not per QP
+        const bool dummy_ip = PI && (status & ISMPC_A_ST_BAD_INDEX);           // a rejected record runs on the stand-in values above
+        const R sq = dummy_ip ? R(1) : (R)(PI ? pre[inst].sqQf : c.sqQf), isq = dummy_ip ? R(1) : (R)(PI ? pre[inst].isqQf : c.isqQf),
+                iQf = dummy_ip ? R(1) : (R)(PI ? pre[inst].iQf : c.iQf);
+        const float rstep = dummy_ip ? 0.5f : (PI ? pre[inst].rstep : c.rstep);
+        const double inv_dsm1 = PI ? (dummy_ip ? 1.0 : pre[inst].inv_dsm1) : 0.0, inv_ds = dummy_ip ? 1.0 : (PI ? pre[inst].inv_ds : c.inv_ds);
+        const double ieta = dummy_ip ? 1.0 : (PI ? pre[inst].ieta : c.ieta);
         const double* fs = PI ? (axis == 0 ? c.plan_x[plan] : c.plan_y[plan]) : (axis == 0 ? c.fsx : c.fsy);
         const double* cl = st.rebuilt ? (axis == 0 ? c.clx1 : c.cly1) : (axis == 0 ? c.clx0 : c.cly0);
         const double cloff = st.rebuilt ? off : 0.0;
@@ -570,7 +574,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             }
         }
         last_inst = (status & ISMPC_A_ST_BAD_INDEX) ? -1 : inst;
-        const R beq = (R)(pos + vel / eta - zmp - tail);
+        const R beq = (R)(pos + vel * ieta - zmp - tail);
         // ---- kinematic row r and footstep f_r (relative to the current one) live in lane r (1..F); Khat_r = sqrt(Qf) (f_r - f_{r-1})
         R fr = R(0), klo = R(-INFINITY), khi = R(INFINITY), muK = R(0);
         int kact = 0;
@@ -1618,9 +1622,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             const double f0 = cur2 + df0;
             double np_, nv_, nz_;
             if (PI) {                                                            // A_upd, B_upd for this instance's eta (:67-71)
-                const double e_ = ppre->lam, ie_ = 1.0 / e_;
-                const double ch = 0.5 * (ie_ + e_), sh = 0.5 * (ie_ - e_);          // cosh, sinh of eta dt
-                np_ = (ch * p0 + (sh / eta2) * v0 + (1 - ch) * z0) + (c.dt - sh / eta2) * u0;
+                const double ch = ppre->ch, sh = ppre->sh, she = ppre->sh_eta;      // cosh, sinh of eta dt (tick prologue)
+                np_ = (ch * p0 + she * v0 + (1 - ch) * z0) + (c.dt - she) * u0;
                 nv_ = ((eta2 * sh) * p0 + ch * v0 + (-eta2 * sh) * z0) + (1 - ch) * u0;
                 nz_ = (0.0 * p0 + 0.0 * v0 + 1.0 * z0) + c.dt * u0;
             } else {
