@@ -301,9 +301,6 @@ __device__ __forceinline__ double cl_closed(const double* __restrict__ fs, int s
 // against 1.95e7 at 2: 14 spilled registers now, 160 before); fp64 3 for two rows per lane (walk C=100: 5.2e7 against 4.3e7 at 2,
 // 8 spilled registers) and for three (walk C=150: 3.44e7 against 3.0e7 at 2, trot C=160 3.0e7 against 2.55e7, with 50 spilled
 // registers); 2 for four rows per lane and for per-instance parameters (LDS).
-#ifndef ISMPC_A_EP               // results a wavefront holds back before it writes them, one lane each (0: every QP writes its own; A/B knob)
-#define ISMPC_A_EP 16
-#endif
 #ifndef ISMPC_A_PAIR_SETUP       // 0: every QP builds its instance's set-up itself (A/B knob)
 #define ISMPC_A_PAIR_SETUP 1
 #endif
@@ -363,14 +360,6 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                                                             // entry in all: the per-instance fp32 shape sits 80 bytes under the LDS of four workgroups per CU)
     __shared__ double pad_s[PI ? 1 : WG + 1], pa2d_s[PI ? 1 : WG + 1];
     __shared__ double pad_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1], pa2d_pi[PI ? WG / 64 : 1][PI ? WG + 1 : 1];
-    // Results held back (u0, first footstep, QP, flags, work): what follows a solve -- LIP update, footstep bookkeeping, the output record:
-    // ~250 vector instructions of fp64 and address arithmetic -- is the work of ONE lane, and a wavefront solves 4-12 QPs per launch.  It
-    // keeps their results here and writes them all at once, lane q the q-th of them (when the buffer is full, and before it exits): the same
-    // instructions serve up to EPN QPs.  Shapes with per-instance parameters have no LDS to spare (the fp32 one at F = 6 sits 80 bytes under
-    // four workgroups per CU): their buffer is the unused tail of the fp64 prefix sums (rows C+1 .. 256), or a single slot when C > 252.
-    constexpr int EPN = ISMPC_A_EP > 0 ? ISMPC_A_EP : 1;
-    __shared__ R ep_r_s[WG / 64][PI ? 2 : 2 * EPN];
-    __shared__ int ep_i_s[WG / 64][PI ? 3 : 3 * EPN];
     // `lane` is re-declared opaque (LANE_FRESH) at the head of every solver phase: comparisons against it (lane == k, lane < m, the
     // fold masks ...) are loop invariants, the compiler hoists dozens of 64-bit masks out of the persistent loop, they do not fit
     // the scalar register file and every use then restores its mask from a spill VGPR lane by lane (two v_readlane and a wait
@@ -381,17 +370,6 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds<R, F>& L = lds_all[wv];
     const int C = c.C, P = c.P;
-    int ecap = (ISMPC_A_EP > 0) ? EPN : 1;
-    R* e_u0 = ep_r_s[wv]; int* e_qp = ep_i_s[wv];
-    if (PI) {
-        const int room = ISMPC_A_EP > 0 ? ((WG - C) * 8) / (int)(2 * sizeof(R) + 12) : 0;
-        ecap = min(room, EPN);
-        if (ecap >= 1) { e_u0 = reinterpret_cast<R*>(pad_pi[PI ? wv : 0] + C + 1); e_qp = reinterpret_cast<int*>(e_u0 + 2 * ecap); }
-        else ecap = 1;
-    }
-    R* e_df = e_u0 + ecap; int* e_sq = e_qp + ecap; int* e_it = e_sq + ecap;
-    int ecnt = 0;
-    bool finishing = false;
     const R dt = (R)c.dt, idt = (R)(1.0 / c.dt), idt2 = (R)(1.0 / (c.dt * c.dt));
     const bool klane = lane >= 1 && lane <= F;            // lane r owns kinematic row r (and f_r)
     for (int k = threadIdx.x; k <= WG; k += WG) rinv[k] = k > 0 ? (R)(1.0 / (double)k) : R(0);
@@ -463,8 +441,7 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             }
             work = dyn_base + claim_cur++;
         }
-        if (work >= total_qp) finishing = true;               // nothing left to claim: write what is held back, then leave
-        if (!finishing) {
+        if (work >= total_qp) break;
         const int qpi = order_is_qp ? order[work] : work;
         const int inst = (order && !order_is_qp) ? order[qpi >> 1] : (qpi >> 1), axis = qpi & 1;
         const int qp = 2 * inst + axis;                    // slot of this QP in the working-set history
@@ -1616,44 +1593,31 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
             }
         }
         LANE_FRESH();
+        // ---- LIP update (:297-322), footstep bookkeeping (:522-556), outputs: fp64 whatever the precision of the solve
 #ifdef ISMPC_A_DIAG
         // bits 0-9 work (as in the product build) | 10-13 block solves | 14-15 why the solve started cold (1 check, 2 budget) |
         // 16-23 ZMP rows active when Goldfarb-Idnani took over | 24-31 partial steps (rows that left inside Goldfarb-Idnani)
         iters = (iters & 1023) | ((dg_ns & 15) << 10) | ((dg_cold & 3) << 14) | ((dg_q0 & 255) << 16) | ((dg_part & 255) << 24);
 #endif
-        {
-            // this QP's results join the ones the wavefront is holding back (slot ecnt)
-            const bool ok = (status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) == 0;
-            const R u0r = ok ? rl(u[0], 0) : R(0);
-            const R df0r = ok ? rl(fr, 1) : R(0);                                 // first footstep, relative to the current one
-            if (lane == 0) { e_u0[ecnt] = u0r; e_df[ecnt] = df0r; e_qp[ecnt] = qp; e_sq[ecnt] = status | ((1 + qz + qk) << 8); e_it[ecnt] = iters; }
-            ++ecnt;
-        }
-        WAVE_LDS_SYNC();
-        }       // (!finishing)
-        // ---- LIP update (:297-322), footstep bookkeeping (:522-556), outputs: fp64 whatever the precision of the solve.  Lane q writes
-        // the q-th result this wavefront holds back.
-        if (ecnt > 0 && (finishing || ecnt >= ecap)) {
-        LANE_FRESH();
-        if (lane < ecnt) {
-            const int qp_l = e_qp[lane], sq_l = e_sq[lane], iters_l = e_it[lane];
-            const double u0 = (double)e_u0[lane], df0 = (double)e_df[lane];
-            const int inst_l = qp_l >> 1, axis_l = qp_l & 1, status_l = sq_l & 255, q = sq_l >> 8;
-            const bool ok = (status_l & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) == 0;
-            // The instance's record is READ AGAIN here, by the lane that writes the results, instead of staying live -- in scalar registers,
-            // it is wave-uniform -- across the whole solve: position, velocity, ZMP, current footstep, counters and (per-instance) the gait
-            // parameters were a quarter of the scalar registers the solver phases had to spill around (round 4).  state_in is the launch's
-            // read-only copy.
-            const ismpc_a_state* sp = state_in + inst_l;
-            const double p0 = axis_l == 0 ? sp->x : sp->y, z0 = axis_l == 0 ? sp->xz : sp->yz, cur2 = axis_l == 0 ? sp->cur_x : sp->cur_y;
-            double v0 = axis_l == 0 ? sp->xd : sp->yd;
-            if (push) v0 += push[inst_l * 2 + axis_l];
+        const bool ok = (status & (ISMPC_A_ST_BAD_INDEX | ISMPC_A_ST_OVERFLOW)) == 0;
+        const double u0 = ok ? (double)rl(u[0], 0) : 0.0;
+        const double df0 = ok ? (double)rl(fr, 1) : 0.0;                          // first footstep, relative to the current one
+        if (lane == 0) {
+            // The instance's record is READ AGAIN here, by this one lane, instead of staying live -- in scalar registers, it is wave-uniform --
+            // across the whole solve: position, velocity, ZMP, current footstep, counters and (per-instance) the gait parameters were a
+            // quarter of the scalar registers the solver phases had to spill around (round 4).  state_in is the launch's read-only copy.
+            const ismpc_a_state* sp = state_in + inst;
+            asm volatile("" : "+v"(sp));                                         // a per-lane address: a vector load of lane 0, not a scalar one
+            const double p0 = axis == 0 ? sp->x : sp->y, z0 = axis == 0 ? sp->xz : sp->yz, cur2 = axis == 0 ? sp->cur_x : sp->cur_y;
+            double v0 = axis == 0 ? sp->xd : sp->yd;
+            if (push) { const double* pp = push + inst * 2 + axis; asm volatile("" : "+v"(pp)); v0 += *pp; }
             const int j2 = sp->j, fc2 = sp->fc;
-            int step2 = c.step, plan2 = 0; double eta2 = c.eta;
+            int step2 = c.step; double eta2 = c.eta;
             const PiPre* ppre = nullptr;
             if (PI) {
-                ppre = pre + inst_l;
-                if (!(status_l & ISMPC_A_ST_BAD_INDEX)) { step2 = ipar[inst_l].step; plan2 = ipar[inst_l].plan; eta2 = ppre->eta; }
+                const ismpc_a_inst* ipp = ipar + inst; asm volatile("" : "+v"(ipp));
+                ppre = pre + inst; asm volatile("" : "+v"(ppre));
+                if (!(status & ISMPC_A_ST_BAD_INDEX)) { step2 = ipp->step; eta2 = ppre->eta; }
             }
             const double f0 = cur2 + df0;
             double np_, nv_, nz_;
@@ -1667,30 +1631,27 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                 nv_ = (c.Au[3] * p0 + c.Au[4] * v0 + c.Au[5] * z0) + c.Bu[1] * u0;
                 nz_ = (c.Au[6] * p0 + c.Au[7] * v0 + c.Au[8] * z0) + c.Bu[2] * u0;
             }
-            ismpc_a_state* so = state + inst_l;
+            ismpc_a_state* so = state + inst;
             const bool stepped = ok && (j2 + 1 >= step2 * fc2);
             if (ok) {
-                if (axis_l == 0) { so->x = np_; so->xd = nv_; so->xz = nz_; } else { so->y = np_; so->yd = nv_; so->yz = nz_; }
+                if (axis == 0) { so->x = np_; so->xd = nv_; so->xz = nz_; } else { so->y = np_; so->yd = nv_; so->yz = nz_; }
                 if (stepped) {
-                    const double* fs2 = PI ? (axis_l == 0 ? c.plan_x[plan2] : c.plan_y[plan2]) : (axis_l == 0 ? c.fsx : c.fsy);
-                    const double noff = f0 - fs2[fc2];
-                    if (axis_l == 0) { so->cur_x = f0; so->off_x = noff; } else { so->cur_y = f0; so->off_y = noff; }
+                    const double noff = f0 - fs[fc2];
+                    if (axis == 0) { so->cur_x = f0; so->off_x = noff; } else { so->cur_y = f0; so->off_y = noff; }
                 }
-                if (axis_l == 0) { so->j = j2 + 1; if (stepped) { so->fc = fc2 + 1; so->rebuilt = 1; } }
+                if (axis == 0) { so->j = j2 + 1; if (stepped) { so->fc = fc2 + 1; so->rebuilt = 1; } }
             }
             if (out) {
-                ismpc_a_out* o = out + inst_l;
-                o->com_before[axis_l] = p0; o->vel_after[axis_l] = ok ? nv_ : v0; o->u0[axis_l] = u0; o->f0[axis_l] = f0;
-                if (axis_l == 0) { o->iters_x = iters_l; atomicOr(&o->status, status_l); atomicOr(&o->active, q & 0xffff); }
-                else { o->iters_y = iters_l; atomicOr(&o->status, status_l); atomicOr(&o->active, (q & 0xffff) << 16); }
+                ismpc_a_out* o = out + inst;
+                const int q = 1 + qz + qk;
+                o->com_before[axis] = p0; o->vel_after[axis] = ok ? nv_ : v0; o->u0[axis] = u0; o->f0[axis] = f0;
+                if (axis == 0) { o->iters_x = iters; atomicOr(&o->status, status); atomicOr(&o->active, q & 0xffff); }
+                else { o->iters_y = iters; atomicOr(&o->status, status); atomicOr(&o->active, (q & 0xffff) << 16); }
             }
-        }
-        ecnt = 0;
         }
         WAVE_LDS_SYNC();
         PH(14);                                            // 14: history, LIP update, outputs
         PH_FLUSH();
-        if (finishing) break;
 #undef W1_
 #undef PN_RESET_
 #undef PN_PRV
