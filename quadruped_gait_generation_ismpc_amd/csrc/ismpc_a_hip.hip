@@ -641,6 +641,15 @@ __global__ void ismpc_a_tick_prologue(const ismpc_a_state* __restrict__ state, i
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 4 && counters) counters[i] = 0;
+    // the snapshot as one flat, coalesced copy of 16-byte words (a thread per record moved six words 96 bytes apart per wavefront access)
+    static_assert(sizeof(ismpc_a_state) % 16 == 0, "state record: whole 16-byte words");
+    {
+        constexpr int WPR = (int)(sizeof(ismpc_a_state) / 16);
+        const double2* src = reinterpret_cast<const double2*>(state);
+        double2* dst = reinterpret_cast<double2*>(prev);
+        const long long nw = (long long)batch * WPR;
+        for (long long w = i; w < nw; w += (long long)gridDim.x * blockDim.x) dst[w] = src[w];
+    }
     if (i >= batch) return;
     if (inst && pre) {
         const double height = inst[i].height;
@@ -662,11 +671,6 @@ __global__ void ismpc_a_tick_prologue(const ismpc_a_state* __restrict__ state, i
         q.ch = 0.5 * (ie + lam); q.sh = 0.5 * (ie - lam); q.sh_eta = q.sh / eta;
         pre[i] = q;
     }
-    static_assert(sizeof(ismpc_a_state) % 16 == 0, "state record: whole 16-byte words");
-    const double2* src = reinterpret_cast<const double2*>(state + i);
-    double2* dst = reinterpret_cast<double2*>(prev + i);
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(ismpc_a_state) / 16); ++k) dst[k] = src[k];
     if (out) { out[i].status = 0; out[i].active = 0; out[i].iters_x = 0; out[i].iters_y = 0; }
 }
 

@@ -340,6 +340,8 @@ void ismpc_a_tick_wave(const DevA* __restrict__ cp, const ismpc_a_state* __restr
                        const int* __restrict__ order, const int* __restrict__ count_ptr, const int claim_chunk_, const int static_q,
                        const int order_is_qp, int* __restrict__ defer_list, int* __restrict__ defer_count, const PiPre* __restrict__ pre)
 {
+    // the re-solve launch behind an fp32 launch that handed nothing over (the usual case) leaves before it builds its tables
+    if (order_is_qp && *count_ptr == 0) return;
     using NM = Num<R>;
     const DevA& c = *cp;                                   // handle constants, read from memory where they are used (by value they would
     constexpr int m = 2 * F + 1;                           // sit in 70 scalar registers for the whole persistent loop)
