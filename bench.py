@@ -254,6 +254,9 @@ class Ranks:
         # all-gather and its event order) runs on a one-GPU box too -- over a group of one rank it moves no bytes between GPUs
         self.collective = self.world > 1 or force_collective
         self.abi = collective == "abi"
+        self.ctl_cpu = self.rehearse or self.abi       # the control plane's tensors live on the host (gloo)
+        self.data_group = None                         # process group of the torch data plane (None: the default one)
+        self.abi_fallback = None                       # why the native group was given up, if it was
         if self.collective:
             import torch.distributed as dist
             self.dist = dist
@@ -272,9 +275,45 @@ class Ranks:
     def max(self, x):
         if self.world == 1:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=("cpu" if (self.rehearse or self.abi) else self.dev))
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=("cpu" if self.ctl_cpu else self.dev))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def agree(self, ok):
+        """True when EVERY rank says ok (one all-reduce over the control plane)."""
+        if self.world == 1:
+            return bool(ok)
+        t = self.torch.tensor([1.0 if ok else 0.0], dtype=self.torch.float64, device=("cpu" if self.ctl_cpu else self.dev))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return t.item() > 0.5
+
+    def native_group(self, make):
+        """make(unique_id) -> the native group of this rank (include/ismpc_group.h).  The group has never run on more than one GPU
+        (DESIGN 6.1): if building it fails on ANY rank, every rank gives it up and torch.distributed's nccl backend (= RCCL) carries
+        the data plane instead -- the round-3 path, measured by the same legs; the line says which one ran (multi_gpu.path)."""
+        if not (self.collective and self.abi) or self.rehearse:
+            return None
+        uid = self.unique_id()
+        grp, why = None, None
+        try:
+            if os.environ.get("ISMPC_BENCH_FAIL_NATIVE_GROUP") == "1":
+                raise RuntimeError("ISMPC_BENCH_FAIL_NATIVE_GROUP=1 (test of the fallback)")
+            with stdout_to_stderr():
+                grp = make(uid)
+        except Exception as e:                           # noqa: BLE001 -- whatever it is, the other ranks must hear about it
+            why = f"{type(e).__name__}: {e}"
+        if self.agree(grp is not None):
+            return grp
+        if grp is not None:
+            try:
+                grp.close()
+            except Exception:                            # noqa: BLE001
+                pass
+        self.abi = False
+        self.abi_fallback = why or "the native group failed on another rank"
+        print(f"bench.py rank {self.rank}: native RCCL group unavailable ({self.abi_fallback}); torch.distributed nccl carries the gather", file=sys.stderr)
+        self.data_group = self.dist.new_group(backend="nccl")
+        return None
 
     def unique_id(self):
         """The communicator's 128 bytes: made by rank 0 (ismpc_group_unique_id), handed to every rank over the control plane."""
@@ -557,13 +596,13 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
         # the product's multi-GPU path: one native group per rank (its own handle, launch stream, side stream, RCCL communicator); the
         # shard's kernel writes into the gathered buffer in place and ONE ncclAllGather completes it on every GPU (csrc/ismpc_group.hip)
         from quadruped_gait_generation_ismpc_amd import group as G
-        with stdout_to_stderr():
-            grp = G.Group.from_rank(q.reference_plan(params=p), p, R.local_rank, R.unique_id(), rank, world)
+        grp = R.native_group(lambda uid: G.Group.from_rank(q.reference_plan(params=p), p, R.local_rank, uid, rank, world))
+    if grp is not None:
         assert grp.world == world and grp.shard(global_batch) == (first, B)
         grp.reserve(global_batch)
         torch.cuda.synchronize()                                         # d_in is complete before the group's own streams read it
     elif R.collective:
-        pipe = GatherPipeline(world, B, 80, device=("cpu" if R.rehearse else R.dev), host_copies=R.rehearse)
+        pipe = GatherPipeline(world, B, 80, device=("cpu" if R.rehearse else R.dev), host_copies=R.rehearse, group=R.data_group)
 
     def step(k):
         if grp is not None:
@@ -657,8 +696,10 @@ def leg_b(R, q, leg, N, global_batch, K, W, min_ms, extras, sweep_sets=0):
             res["multi_gpu"] = {"rccl_world": grp.world, "rccl_version": G.rccl_version(), "path": "abi", "kernel_ms": kernel_ms_train,
                                 "exposed_collective_ms": collective_ms, "overlapped_step_ms": 1e3 * wall / K}
         if pipe is not None:
-            res["multi_gpu"] = {"rccl_world": (R.dist.get_world_size() if not R.rehearse else None), "path": "torch", "kernel_ms": kernel_ms_train,
+            res["multi_gpu"] = {"rccl_world": (R.dist.get_world_size(R.data_group) if not R.rehearse else None), "path": "torch", "kernel_ms": kernel_ms_train,
                                 "collective_ms": collective_ms, "overlapped_step_ms": 1e3 * wall / K}
+            if R.abi_fallback:
+                res["multi_gpu"]["native_group_failed"] = R.abi_fallback[:48]
         if extras and world == 1:
             # PCIe-inclusive rate through the host-pointer entry point (H2D of the inputs and D2H of the outputs
             # inside the metric) -- never `value`.  Page-locked caller buffers: zero copy (the kernel reads and writes them in place
@@ -841,11 +882,14 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
     if R.collective and R.abi and not R.rehearse:
         # the native group (include/ismpc_group.h): this rank's `batch` instances are shard `rank` of a global batch of world x batch
         from quadruped_gait_generation_ismpc_amd import group as G
-        with stdout_to_stderr():
+
+        def make_group(uid):
             if name == "mc_C200":
-                ga = G.GroupA.from_rank(FA.default_params(0, C=Cn, P=Pn, F=Fn), plans[0], R.local_rank, R.unique_id(), rank, world); ga.add_plan(plans[1])
-            else:
-                ga = G.GroupA.from_rank(FA.default_params(w["kind"], C=Cn, P=Pn, F=Fn), ce, R.local_rank, R.unique_id(), rank, world)
+                g_ = G.GroupA.from_rank(FA.default_params(0, C=Cn, P=Pn, F=Fn), plans[0], R.local_rank, uid, rank, world); g_.add_plan(plans[1])
+                return g_
+            return G.GroupA.from_rank(FA.default_params(w["kind"], C=Cn, P=Pn, F=Fn), ce, R.local_rank, uid, rank, world)
+        ga = R.native_group(make_group)
+    if ga is not None:
         ga.set_precision(dtype == "f32")
         assert ga.world == world and ga.shard(world * batch) == (rank * batch, batch)
         ga.reserve(world * batch)
@@ -883,7 +927,7 @@ def leg_a(R, q, leg, name, batch, K, W, min_ms, dtype="f64"):
         o = tick(state_of(k), dpush)
         last[0] = o
         if all_out is not None:
-            gather_records(o.cpu() if R.rehearse else o, world, out=all_out, counts=[batch] * world, force=True)
+            gather_records(o.cpu() if R.rehearse else o, world, out=all_out, counts=[batch] * world, force=True, group=R.data_group)
 
     def step_timed(k):                                                   # the same tick between two events: kernel_ms (untimed pass)
         dk = state_of(k)

@@ -33,14 +33,19 @@ def test_one_rank_rccl_group_runs_the_gather_pipeline(built_libs):
     assert d["pipeline_bytes_ok"] and d["gather_records_ok"] and d["status_ok_fraction"] > 0.5
 
 
-@pytest.mark.parametrize("collective", ["abi", "torch"])
+@pytest.mark.parametrize("collective", ["abi", "torch", "abi_fails"])
 def test_bench_gpus_1_through_its_own_launcher_with_the_collective(built_libs, collective):
     """`bench.py --gpus 1 --spawn --force-collective`: the launcher path of `--gpus N` with a one-rank group.  abi (default): the native
     library's own communicator (ismpc_group_create_rank from a unique id handed over the gloo control plane, ismpc_group_step_device);
     torch: torch.distributed's nccl backend through GatherPipeline (round 3's path, kept for A/B)."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--force-collective", "--collective", collective,
+    # abi_fails: the native group cannot be built (simulated) -- every rank must agree to give it up and the torch path carries the gather
+    env = _env()
+    fails = collective == "abi_fails"
+    if fails:
+        env["ISMPC_BENCH_FAIL_NATIVE_GROUP"] = "1"; collective = "torch"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--force-collective", "--collective", "abi" if fails else collective,
                         "--only", "shard_b8192", "--no-cpu-baseline", "--no-extras", "--full-line", "--steps", "10", "--warmup", "3", "--min-region-ms", "5"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=_env())
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -49,6 +54,7 @@ def test_bench_gpus_1_through_its_own_launcher_with_the_collective(built_libs, c
     mg = d["multi_gpu"]
     assert mg["path"] == collective and mg["rccl_world"] == 1                                   # what RCCL itself reports (abi) / torch's world (torch)
     assert mg["kernel_ms"] > 0 and mg["overlapped_step_ms"] > 0
+    assert ("native_group_failed" in mg) == fails
     if collective == "torch":
         assert mg["collective_ms"] is not None and mg["collective_ms"] > 0
     else:
