@@ -77,4 +77,5 @@ if [ $ALL -eq 1 ] || [ $ONLY_FINAL -eq 1 ]; then
   timeout -k 10 900 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/driver_cmd_bench_line.json 2> $OUT/bench_full.err || { tail -5 $OUT/bench_full.err; exit 1; }
   cp $R/bench_detail.json $OUT/bench_full_line.json
   [ -x $R/build/valu_peak ] && $R/build/valu_peak > $OUT/valu_peak.json
+  [ -x $R/build/launch_floor ] && $R/build/launch_floor > $OUT/launch_floor.json      # what a launch costs before it does any work (scripts/micro/launch_floor.hip)
 fi
